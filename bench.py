@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — the hot-path benchmark (BASELINE.json metric: depth-maps/sec at 304x228 b=24, 24 CSPN iters;
+achieved HBM GB/s vs roofline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM: the module
+forward `AffinityPropagate(24, 3)(guidance[24,12,228,304], coarse[24,1,228,304])` (prepare + 24 propagation
+steps, all in libcspn_hip.so) plus the fused depth-metrics reduction of the refined batch.  N > 1: one
+process per GPU, every rank refines its own batch (weak scaling, no collective inside the loop), one RCCL
+all-gather of the 10 metric sums at the end of the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import cspn_monodepth_amd as pkg                      # noqa: E402
+from cspn_monodepth_amd import functional as F        # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    # name: (B per GPU, H, W, K, T, dtype, guidance channels)
+    "nyu": dict(B=24, H=228, W=304, K=3, T=24, dtype="f32", C=12,
+                name="NYU-v2 304x228 batch=24, 24-iter 3x3 CSPN (BASELINE config 2)"),
+    "kitti": dict(B=8, H=352, W=1216, K=3, T=24, dtype="f32", C=12,
+                  name="KITTI 1216x352 batch=8 sharded over the ranks, 24-iter 3x3 CSPN (BASELINE config 4)"),
+    "pac5": dict(B=24, H=228, W=304, K=5, T=12, dtype="f16", C=24,
+                 name="NYU-v2 304x228 batch=24, 5x5 softmax affinity, 12 iters, fp16 (BASELINE config 3)"),
+}
+
+
+def parse_plan(txt):
+    if not txt:
+        return None
+    keys = ("steps_per_launch", "tile_w", "tile_h", "quads_per_thread", "threads")
+    return {k: int(v) for k, v in zip(keys, txt.split(","))}
+
+
+def make_inputs(wl, B, device, seed, sparse):
+    """SURVEY.md §8(d) value distributions (synthetic; no dataset on the box)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    dt = torch.float16 if wl["dtype"] == "f16" else torch.float32
+    g = torch.randn(B, wl["C"], wl["H"], wl["W"], device=device, generator=gen).to(dt)
+    d = (torch.rand(B, 1, wl["H"], wl["W"], device=device, generator=gen) * 10).to(dt)
+    s = None
+    if sparse:
+        keep = torch.rand(B, 1, wl["H"], wl["W"], device=device, generator=gen) < 500.0 / (wl["H"] * wl["W"])
+        s = (d * keep).to(dt)
+    noise = torch.randn(B, 1, wl["H"], wl["W"], device=device, generator=gen) * 0.1
+    target = (d.float() + noise).clamp_min(0.05)
+    target = torch.where(torch.rand(B, 1, wl["H"], wl["W"], device=device, generator=gen) < 0.05,
+                         torch.zeros_like(target), target).to(dt)
+    return g, d, s, target
+
+
+def cpu_baseline(wl, budget_s=15.0):
+    """The reference's CPU op mix (oracle/ref_plumbing_torch.py, a port validated bit-identical to the imported
+    reference) on this box's host cores, bounded sample of the same workload."""
+    from oracle import ref_plumbing_torch as plumb
+    from oracle import c_oracle
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    B, H, W, T = wl["B"], wl["H"], wl["W"], wl["T"]
+    torch.manual_seed(0)
+    if wl["K"] == 3:
+        g, d = torch.randn(B, 8, H, W), torch.rand(B, 1, H, W) * 10
+        fn = lambda: plumb.cspn3_plumbing(g, d, None, T)           # noqa: E731
+    else:
+        g, d = torch.randn(B, wl["C"], H, W), torch.rand(B, 1, H, W) * 10
+        fn = lambda: plumb.pac_plumbing(d, g, None, T)             # noqa: E731
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        fn()                                                       # warm-up (also sizes the sample)
+        first = time.perf_counter() - t0
+        reps = max(1, min(5, int(budget_s / max(first, 1e-3))))
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    out = {"value": B / med, "unit": "depth-maps/s", "cores": threads, "kind": "port",
+           "sample": "%d forward(s) of the full workload (B=%d, %dx%d, T=%d) after 1 warm-up, median; PyTorch %s CPU "
+                     "op-mix port of the reference (pad/cat/conv3d-ones/div)" % (reps, B, W, H, T, torch.__version__)}
+    # the scalar C oracle on one core, for calibration
+    try:
+        import numpy as np
+        if wl["K"] == 3:
+            gn, dn, _ = c_oracle.synthetic_inputs(0, 4, H, W, 8, None)
+            t0 = time.perf_counter()
+            c_oracle.cspn3_forward(gn, dn, None, T)
+            out["c_oracle_1core_maps_per_s"] = 4 / (time.perf_counter() - t0)
+        del np
+    except Exception as e:  # pragma: no cover
+        out["c_oracle_error"] = repr(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="nyu", choices=sorted(WORKLOADS))
+    ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
+    ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+
+    wl = dict(WORKLOADS[args.workload])
+    strong = args.workload == "kitti"
+    if strong:                                        # config 4: the batch of 8 is sharded across the ranks
+        lo, hi = pkg.evaluation.shard_bounds(wl["B"], rank, world)
+        B_local = hi - lo
+    else:
+        B_local = wl["B"]
+    plan = parse_plan(args.plan)
+    K, T = wl["K"], wl["T"]
+    g, d, s, target = make_inputs(wl, max(B_local, 1), device, seed=1234 + rank, sparse=args.sparse)
+    if K == 3:
+        module = pkg.CSPN_new.AffinityPropagate(T, 3, plan=plan)
+        run = lambda: module(g, d, s)                                  # noqa: E731
+    else:
+        module = pkg.CSPN_ours.AffinityPropagate(T, plan=plan, state_dtype=None)
+        run = lambda: module(d, g, s)                                  # noqa: E731
+    eff_plan = F.resolve_plan(K, B_local, wl["H"], wl["W"], T, False, plan)
+    sums = torch.zeros(pkg.evaluation.N_SUMS, dtype=torch.float64, device=device)
+
+    def step():
+        out = run()
+        if not args.no_metrics:
+            pkg.evaluation.metric_sums(out, target, out=sums)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        sums.zero_()
+        events = []
+        F.set_event_log(events)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        total, per_rank = pkg.evaluation.all_gather_metric_sums(sums)  # the only collective: 10 float64 per rank
+        fence()
+        t1 = time.perf_counter()
+        F.set_event_log(None)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # ---- roofline of the dominant kernel (the propagation kernel), from HIP events on the launch stream
+    prop_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in events)
+    n_launch = sum(n for _, _, n, _ in events)
+    S = eff_plan["steps_per_launch"]
+    esz = 2 if wl["dtype"] == "f16" else 4
+    bytes_px_step = (K * K + 1) * esz + (2 * esz if args.sparse else 0)
+    alg_bytes_per_launch = bytes_px_step * B_local * wl["H"] * wl["W"] * (T / max(1, -(-T // S)))
+    avg_launch_s = (prop_ms / 1e3) / max(n_launch, 1)
+    achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    maps_total = (wl["B"] if strong else wl["B"] * world) * args.steps
+    if rank == 0:
+        res = {
+            "metric": "depth-maps/sec at 304x228 b=24, 24 CSPN iters" if args.workload == "nyu"
+                      else "depth-maps/sec (%s)" % wl["name"],
+            "value": maps_total / elapsed,
+            "unit": "depth-maps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
+            "dtype": wl["dtype"],
+            "data": "synthetic (guidance~N(0,1), coarse~U(0,10)m%s; inputs resident in HBM)" % (
+                ", 500-sample sparse depth" if args.sparse else ""),
+            "config": {"workload": wl["name"], "batch_per_gpu": B_local, "H": wl["H"], "W": wl["W"], "K": K,
+                       "prop_time": T, "guidance_channels": wl["C"], "sparse": bool(args.sparse),
+                       "step": "prepare + %d propagation steps%s" % (T, "" if args.no_metrics else " + metrics reduction"),
+                       "plan": eff_plan, "parallelism": "batch-shard x%d, metrics all-gather" % world},
+            "roofline": {"bound": "hbm", "kernel": "cspn_prop_fused", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": n_launch,
+                         "steps_per_launch": S, "bytes_per_px_step": bytes_px_step,
+                         "note": "HIP events around each propagation loop inside the timed region (launch gaps "
+                                 "included) / launches; S>1 = temporal blocking, so algorithmic bytes per launch "
+                                 "exceed what the launch reads from HBM"},
+            "metrics_check": {k: v for k, v in pkg.evaluation.finalize_metrics(total.cpu()).items()
+                              if k in ("rmse", "absrel", "delta1", "count")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(wl)
+            except Exception as e:  # pragma: no cover
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""Loader / builder of libcspn_hip.so (the C-ABI HIP engine, include/cspn_hip.h).
+
+The reference loaded its native code through torch.utils.ffi (network/libs/inplace_abn/build.py:3-21,
+_ext/__init__.py:2-13 — removed from PyTorch 1.0); here it is a plain ``ctypes.CDLL``.
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised
+(the reference's ``_check`` does the same, inplace_abn/functions.py:13-16).
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SO_PATH = os.path.join(_PKG, "libcspn_hip.so")
+SRC = os.path.join(_PKG, "csrc", "cspn_kernels.hip")
+INCLUDE = os.path.join(_ROOT, "include")
+
+CSPN_F32, CSPN_F16 = 0, 1
+BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
+
+# every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
+    "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_transpose_weights",
+    "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn_metrics_accumulate",
+)
+
+
+class cspn_plan(ctypes.Structure):
+    _fields_ = [("steps_per_launch", ctypes.c_int), ("tile_w", ctypes.c_int), ("tile_h", ctypes.c_int),
+                ("quads_per_thread", ctypes.c_int), ("threads", ctypes.c_int), ("force_scalar", ctypes.c_int)]
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU.  In-tree output (travels with gpurun snapshots)."""
+    deps = [SRC, os.path.join(INCLUDE, "cspn_hip.h")]
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fno-fast-math", "-I", INCLUDE, "-o", SO_PATH + ".tmp", SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    return SO_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _declare(lib):
+    vp, ci, cl, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+    lib.cspn_abi_version.restype = ci
+    lib.cspn_last_error.restype = ctypes.c_char_p
+    lib.cspn_plan_resolve.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_plan), ctypes.POINTER(cspn_plan)]
+    lib.cspn3_prepare.argtypes = [vp, ci, cl, cl, ci, ci, ci, vp, ci, vp, vp]
+    lib.cspn_pac_prepare.argtypes = [vp, ci, ci, ci, ci, ci, vp, ci, vp]
+    lib.cspn_propagate_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci]
+    lib.cspn_propagate_workspace_bytes.restype = cs
+    lib.cspn_propagate.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
+                                   ctypes.POINTER(cspn_plan), vp]
+    lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
+    lib.cspn_pac_grad_guided.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes"):
+            fn.restype = ci
+    return lib
+
+
+def lib():
+    """The loaded engine.  Raises RuntimeError (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(SO_PATH):
+                    raise RuntimeError(
+                        "cspn_monodepth_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % SO_PATH)
+                _lib = _declare(ctypes.CDLL(SO_PATH))
+                if _lib.cspn_abi_version() != 1:
+                    raise RuntimeError("cspn_monodepth_amd: ABI version mismatch")
+    return _lib
+
+
+def check(ok, what):
+    """Truthy = success, as the reference's native convention (inplace_abn/functions.py:13-16)."""
+    if not ok:
+        raise RuntimeError("%s failed: %s" % (what, lib().cspn_last_error().decode()))

@@ -1,0 +1,903 @@
+// cspn_kernels.hip — CDNA4 (gfx950) kernels + C ABI of the CSPN affinity-propagation engine.
+//
+// The hot path is the recurrence  d_{t+1}[p] = blend( sum_j w_j[p] * d_t[p + off_j] )  over the
+// K*K-1 non-centre taps of a K x K window (reference: network/libs/post_process/CSPN_new.py:80-90
+// for K=3 with sum-normalised neighbour-indexed gates, CSPN_ours.py:47-53 + base/pac.py:89-92 for
+// softmax-normalised centre-indexed taps).  It is a (K*K+1)*sizeof(T) bytes/pixel/step stream with
+// ~0.4 flop/byte: HBM/L2-bandwidth bound, no MFMA.  Design:
+//   * one launch = S consecutive propagation steps of one tile ("temporal blocking", S >= 1);
+//   * each thread owns NQ vertically consecutive 4-pixel quads and keeps their K*K-1 weights in
+//     VGPRs for all S steps (the weight volume is the only large stream: it is read once per launch
+//     with 16-byte coalesced loads issued before anything else);
+//   * the depth tile + halo lives in LDS (ping-pong), neighbours are exchanged through LDS between
+//     the wavefronts of the workgroup, one barrier per step;
+//   * blockIdx -> tile mapping is XCD-aware: every XCD (b % 8) walks a contiguous range of tiles, so
+//     halo re-reads and the depth written by the previous launch hit that XCD's private L2.
+// No fast-math: the reference's 0/0 = NaN semantics (CSPN_new.py:127) must survive.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "cspn_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 0;
+}
+
+#define HIP_OK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// element access helpers: everything is computed in fp32, storage is f32 or f16
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __half* p) {
+    const uint2 raw = *reinterpret_cast<const uint2*>(p);
+    const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+    const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__half* p, float4 v) {
+    uint2 raw;
+    *reinterpret_cast<__half2*>(&raw.x) = __floats2half2_rn(v.x, v.y);
+    *reinterpret_cast<__half2*>(&raw.y) = __floats2half2_rn(v.z, v.w);
+    *reinterpret_cast<uint2*>(p) = raw;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v); }
+
+__device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+__device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
+
+// blockIdx -> logical tile id such that XCD x (= blockIdx % 8, observed dispatch order; speed only,
+// never correctness) processes one contiguous range of tiles.
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int x = bid & 7, j = bid >> 3;
+    return x * q + (x < r ? x : r) + j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused propagation kernel
+// ------------------------------------------------------------------------------------------------
+struct PropArgs {
+    const void* w;       // [B,NT,H,W]
+    const void* d_in;    // [B,H,W]
+    void* d_out;         // [B,H,W] state after the last fused step (may be null when hist != null)
+    void* hist;          // null, or plane s-1 (stride B*H*W) receives the state after fused step s
+    const void* sparse;  // [B,H,W] (blend 1, 2)
+    const void* d0;      // [B,H,W] (blend 1)
+    int B, H, W, S;
+    int tw, th, tiles_x, tiles_y;
+    int wq, wr;          // weight region: quad columns, rows
+    int hxw, hyw;        // weight-region halo (pixels) left/right, top/bottom
+    int dr, ls;          // depth region rows, LDS row stride (floats)
+};
+
+template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND>
+__global__ __launch_bounds__(NTHREADS) void cspn_prop_fused(const PropArgs a) {
+    constexpr int R = K / 2;
+    constexpr int NT = K * K - 1;
+    constexpr int WIN = 4 + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int tile = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int b = tile / tiles_per_img;
+    const int trem = tile - b * tiles_per_img;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int H = a.H, W = a.W;
+    const int y0 = ty * a.th, x0 = tx * a.tw;
+    const size_t HW = (size_t)H * W;
+    const size_t plane = (size_t)a.B * HW;
+
+    const WT* __restrict__ wg = static_cast<const WT*>(a.w) + (size_t)b * NT * HW;
+    const DT* __restrict__ din = static_cast<const DT*>(a.d_in) + (size_t)b * HW;
+    const DT* __restrict__ spg = BLEND ? static_cast<const DT*>(a.sparse) + (size_t)b * HW : nullptr;
+
+    // ---- ownership: strip (sx, sy) = NQ vertically consecutive quads of the weight region -------
+    const int wq = a.wq, wr = a.wr;
+    const int sy = tid / wq;
+    const int sx = tid - sy * wq;
+    const int r0 = sy * NQ;                    // first weight-region row of this strip
+    const int xq = x0 - a.hxw + 4 * sx;        // image x of the quad
+    const int yq0 = y0 - a.hyw + r0;           // image y of the first quad
+    const bool x_in = (xq >= 0) && (xq < W);   // W % 4 == 0: a quad is fully inside or outside
+
+    // ---- 1. issue the weight stream first (independent of LDS): NQ x NT 16-byte loads -----------
+    float wreg[NQ][NT][4];
+    float mreg[NQ][4], d0reg[NQ][4];
+    unsigned in_img = 0, interior = 0;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int r = r0 + i, y = yq0 + i;
+        const bool ok = (r < wr) && x_in && (y >= 0) && (y < H);
+        if (ok) in_img |= 1u << i;
+        if (ok && r >= a.hyw && r < a.hyw + a.th && xq >= x0 && xq < x0 + a.tw) interior |= 1u << i;
+        const size_t off = (size_t)(ok ? y : 0) * W + (ok ? xq : 0);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float4 v = ok ? ld4(wg + (size_t)j * HW + off) : z4;
+            wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
+        }
+        if (BLEND) {
+            const float4 v = ok ? sgn4(ld4(spg + off)) : z4;
+            mreg[i][0] = v.x; mreg[i][1] = v.y; mreg[i][2] = v.z; mreg[i][3] = v.w;
+        }
+        if (BLEND == CSPN_BLEND_SPARSE) {
+            const float4 v = ok ? ld4(static_cast<const DT*>(a.d0) + (size_t)b * HW + off) : z4;
+            d0reg[i][0] = v.x; d0reg[i][1] = v.y; d0reg[i][2] = v.z; d0reg[i][3] = v.w;
+        }
+    }
+
+    // ---- 2. stage the depth region (weight region + R halo) into LDS ----------------------------
+    const int dr = a.dr, ls = a.ls;
+    float* cur = lds;
+    float* nxt = lds + (size_t)dr * ls;
+    const int yd0 = y0 - a.hyw - R;            // image y of depth-region row 0
+    const int xd0 = x0 - a.hxw - 4;            // image x of LDS column 0
+    for (int idx = tid; idx < dr * wq; idx += NTHREADS) {
+        const int row = idx / wq, qx = idx - row * wq;
+        const int y = yd0 + row, x = xd0 + 4 + 4 * qx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            v = ld4(din + (size_t)y * W + x);
+            if (BLEND == CSPN_BLEND_PREMASK) {
+                const float4 m = sgn4(ld4(spg + (size_t)y * W + x));
+                v.x *= 1.f - m.x; v.y *= 1.f - m.y; v.z *= 1.f - m.z; v.w *= 1.f - m.w;
+            }
+        }
+        *reinterpret_cast<float4*>(&cur[row * ls + 4 + 4 * qx]) = v;
+    }
+    for (int idx = tid; idx < dr * 2 * R; idx += NTHREADS) {
+        const int row = idx / (2 * R), c = idx - row * (2 * R);
+        const int lc = (c < R) ? (4 - R + c) : (4 + 4 * wq + (c - R));
+        const int y = yd0 + row, x = xd0 + lc;
+        float v = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            v = ld1(din + (size_t)y * W + x);
+            if (BLEND == CSPN_BLEND_PREMASK) v *= 1.f - sgnf(ld1(spg + (size_t)y * W + x));
+        }
+        cur[row * ls + lc] = v;
+        nxt[row * ls + lc] = 0.f;   // the outer halo ring of the second buffer is never computed
+    }
+    __syncthreads();
+
+    // ---- 3. S propagation steps in LDS ------------------------------------------------------------
+    const bool active = (r0 < wr);
+    const int cb = 4 + 4 * sx;
+    DT* __restrict__ dout = a.d_out ? static_cast<DT*>(a.d_out) + (size_t)b * HW : nullptr;
+    DT* __restrict__ hist = a.hist ? static_cast<DT*>(a.hist) + (size_t)b * HW : nullptr;
+
+    for (int s = 1; s <= a.S; ++s) {
+        const bool last = (s == a.S);
+        if (active) {
+            float win[NQ + 2 * R][WIN];
+#pragma unroll
+            for (int rr = 0; rr < NQ + 2 * R; ++rr) {
+                int drow = r0 + rr;
+                drow = drow < dr ? drow : dr - 1;
+                const float* rowp = cur + drow * ls + cb;
+                const float4 mid = *reinterpret_cast<const float4*>(rowp);
+#pragma unroll
+                for (int c = 0; c < R; ++c) win[rr][c] = rowp[c - R];
+                win[rr][R + 0] = mid.x; win[rr][R + 1] = mid.y; win[rr][R + 2] = mid.z; win[rr][R + 3] = mid.w;
+#pragma unroll
+                for (int c = 0; c < R; ++c) win[rr][R + 4 + c] = rowp[4 + c];
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (r0 + i < wr) {
+                    float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+                        for (int dx = -R; dx <= R; ++dx) {
+                            if (dy == 0 && dx == 0) continue;
+                            const int lin = (dy + R) * K + (dx + R);
+                            const int j = lin < (K * K) / 2 ? lin : lin - 1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                u[e] = fmaf(wreg[i][j][e], win[i + dy + R][e + dx + R], u[e]);
+                        }
+                    float keep[4];   // value carried to the next step through LDS
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (BLEND == CSPN_BLEND_SPARSE) {
+                            u[e] = (1.f - mreg[i][e]) * u[e] + mreg[i][e] * d0reg[i][e];
+                            keep[e] = u[e];
+                        } else if (BLEND == CSPN_BLEND_PREMASK) {
+                            keep[e] = (1.f - mreg[i][e]) * u[e];
+                        } else {
+                            keep[e] = u[e];
+                        }
+                        if (!((in_img >> i) & 1u)) { u[e] = 0.f; keep[e] = 0.f; }   // zero padding stays exactly zero
+                    }
+                    if (!last)
+                        *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) =
+                            make_float4(keep[0], keep[1], keep[2], keep[3]);
+                    if ((interior >> i) & 1u) {
+                        const size_t off = (size_t)(yq0 + i) * W + xq;
+                        const float4 uv = make_float4(u[0], u[1], u[2], u[3]);
+                        if (hist) st4(hist + (size_t)(s - 1) * plane + off, uv);
+                        else if (last) st4(dout + off, uv);
+                    }
+                }
+            }
+        }
+        if (!last) {
+            __syncthreads();
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+}
+
+// Generic one-pixel-per-thread step (any W, any alignment, S = 1).  Correctness path for shapes the
+// vector kernel cannot take (W % 4 != 0); not the tuned path.
+template <int K, typename WT, typename DT, int BLEND>
+__global__ void cspn_prop_scalar(const void* w_, const void* din_, void* dout_, const void* sp_,
+                                 const void* d0_, int B, int H, int W) {
+    constexpr int R = K / 2;
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    const WT* w = static_cast<const WT*>(w_);
+    const DT* din = static_cast<const DT*>(din_);
+    const DT* sp = static_cast<const DT*>(sp_);
+    const DT* d0 = static_cast<const DT*>(d0_);
+    DT* dout = static_cast<DT*>(dout_);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i - (size_t)b * HW);
+        const int y = p / W, x = p - y * W;
+        float u = 0.f;
+        int j = 0;
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dx = -R; dx <= R; ++dx) {
+                if (dy == 0 && dx == 0) continue;
+                const int yy = y + dy, xx = x + dx;
+                float dv = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    dv = ld1(din + (size_t)b * HW + (size_t)yy * W + xx);
+                    if (BLEND == CSPN_BLEND_PREMASK) dv *= 1.f - sgnf(ld1(sp + (size_t)b * HW + (size_t)yy * W + xx));
+                }
+                u = fmaf(ld1(w + ((size_t)b * NT + j) * HW + p), dv, u);
+                ++j;
+            }
+        if (BLEND == CSPN_BLEND_SPARSE) {
+            const float m = sgnf(ld1(sp + i));
+            u = (1.f - m) * u + m * ld1(d0 + i);
+        }
+        st1(dout + i, u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepare kernels (run once per forward)
+// ------------------------------------------------------------------------------------------------
+// 3x3: w_j[p] = |g_{7-j}[p+off_j]| / S[p],  S[p] = sum_{k=0..7} |g_k[p+o_k]| summed in the
+// reference's channel order k = 0..7 (CSPN_new.py:29-70, :124-127).  True IEEE division.
+template <typename GT, typename WT>
+__global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs, int B, int H, int W,
+                                     WT* __restrict__ w8, float* __restrict__ s_out) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i - (size_t)b * HW);
+        const int y = p / W, x = p - y * W;
+        const GT* gb = g + (size_t)b * bs;
+        float a[8];
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // reference plane k samples at o_k = -(off of tap k) ... tap j = 7-k, off_j row-major
+            const int j = 7 - k;
+            const int lin = j < 4 ? j : j + 1;
+            const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+            const int yy = y + dy, xx = x + dx;
+            float v = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = fabsf(ld1(gb + (size_t)k * cs + (size_t)yy * W + xx));
+            a[j] = v;
+            S = (k == 0) ? v : S + v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st1(w8 + ((size_t)b * 8 + j) * HW + p, a[j] / S);
+        if (s_out) s_out[i] = S;
+    }
+}
+
+// K x K: softmax over the K*K-1 channels at the centre pixel (CSPN_ours.py:35); tap j = channel j.
+template <int K, typename GT, typename WT>
+__global__ void cspn_pac_prepare_kernel(const GT* __restrict__ g, int B, int H, int W, WT* __restrict__ wk) {
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const size_t p = i - (size_t)b * HW;
+        const GT* gb = g + (size_t)b * NT * HW + p;
+        float v[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { v[c] = ld1(gb + (size_t)c * HW); mx = fmaxf(mx, v[c]); }
+        float den = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { v[c] = expf(v[c] - mx); den += v[c]; }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) st1(wk + ((size_t)b * NT + c) * HW + p, v[c] / den);
+    }
+}
+
+// wT_j[q] = w_{NT-1-j}[q + off_j]  (0 outside)
+template <int K, typename WT>
+__global__ void cspn_transpose_kernel(const WT* __restrict__ w, WT* __restrict__ wT, int B, int H, int W) {
+    constexpr int R = K / 2;
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i - (size_t)b * HW);
+        const int y = p / W, x = p - y * W;
+        int j = 0;
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dx = -R; dx <= R; ++dx) {
+                if (dy == 0 && dx == 0) continue;
+                const int yy = y + dy, xx = x + dx;
+                float v = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                    v = ld1(w + ((size_t)b * NT + (NT - 1 - j)) * HW + (size_t)yy * W + xx);
+                st1(wT + ((size_t)b * NT + j) * HW + p, v);
+                ++j;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward helpers
+// ------------------------------------------------------------------------------------------------
+// gw_j[p] = (1-m) sum_t G_{t+1}[p] d_t[p+off_j];  gd0[p] = G_0[p] + m sum_{t>=1} G_t[p]
+template <int K, typename DT>
+__global__ void cspn_grad_weights_kernel(const DT* __restrict__ d0, const DT* __restrict__ dhist,
+                                         const float* __restrict__ ghist, const DT* __restrict__ sparse,
+                                         float* __restrict__ gw, float* __restrict__ gd0,
+                                         int B, int H, int W, int T) {
+    constexpr int R = K / 2;
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i - (size_t)b * HW);
+        const int y = p / W, x = p - y * W;
+        float acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = 0.f;
+        float gsum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const DT* d = (t == 0) ? d0 : dhist + (size_t)(t - 1) * total;
+            const float G = ghist[(size_t)(T - 1 - t) * total + i];   // G_{t+1}
+            gsum += G;
+            int j = 0;
+#pragma unroll
+            for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+                for (int dx = -R; dx <= R; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const int yy = y + dy, xx = x + dx;
+                    float dv = 0.f;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) dv = ld1(d + (size_t)b * HW + (size_t)yy * W + xx);
+                    acc[j] = fmaf(G, dv, acc[j]);
+                    ++j;
+                }
+        }
+        const float m = sparse ? sgnf(ld1(sparse + i)) : 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) gw[((size_t)b * NT + j) * HW + p] = (1.f - m) * acc[j];
+        gd0[i] = ghist[(size_t)T * total + i] + m * gsum;        // G_0 + m sum_{t>=1} G_t
+    }
+}
+
+// dL/dg_{7-j}[q] = sign(g) * gA_j[q - off_j],  gA_j = (gw_j - sum_k gw_k w_k) / S
+template <typename GT, typename WT>
+__global__ void cspn3_grad_guidance_kernel(const GT* __restrict__ g, long bs, long cs, int C,
+                                           const WT* __restrict__ w8, const float* __restrict__ S,
+                                           const float* __restrict__ gw, GT* __restrict__ gg,
+                                           int B, int H, int W) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int q = (int)(i - (size_t)b * HW);
+        const int y = q / W, x = q - y * W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+            const int yy = y - dy, xx = x - dx;       // p = q - off_j
+            float val = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const size_t p = (size_t)yy * W + xx;
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    dot = fmaf(gw[((size_t)b * 8 + k) * HW + p], ld1(w8 + ((size_t)b * 8 + k) * HW + p), dot);
+                const float gA = (gw[((size_t)b * 8 + j) * HW + p] - dot) / S[(size_t)b * HW + p];
+                val = sgnf(ld1(g + (size_t)b * bs + (size_t)(7 - j) * cs + q)) * gA;
+            }
+            st1(gg + (size_t)b * bs + (size_t)(7 - j) * cs + q, val);
+        }
+        for (int c = 8; c < C; ++c) st1(gg + (size_t)b * bs + (size_t)c * cs + q, 0.f);
+    }
+}
+
+template <int K, typename WT, typename GT>
+__global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const float* __restrict__ gw,
+                                            GT* __restrict__ gg, int B, int H, int W) {
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const size_t p = i - (size_t)b * HW;
+        float sm[NT], gv[NT];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            sm[c] = ld1(wk + ((size_t)b * NT + c) * HW + p);
+            gv[c] = gw[((size_t)b * NT + c) * HW + p];
+            dot = fmaf(sm[c], gv[c], dot);
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) st1(gg + ((size_t)b * NT + c) * HW + p, sm[c] * (gv[c] - dot));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// evaluation metrics: masked sums (libs/metrics.py:49-83)
+// ------------------------------------------------------------------------------------------------
+template <typename DT>
+__global__ void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __restrict__ target, size_t n,
+                                    double* __restrict__ acc) {
+    double s[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = ld1(target + i);
+        if (!(t > 0.f)) continue;
+        const float o = ld1(pred + i);
+        const float ad = fabsf(o - t);
+        const float inv = fabsf(1.f / o - 1.f / t);
+        const float ratio = fmaxf(o / t, t / o);
+        s[0] += (double)inv * inv;
+        s[1] += inv;
+        s[2] += (double)ad * ad;
+        s[3] += ad;
+        s[4] += ad / t;
+        s[5] += fabsf(log10f(o) - log10f(t));
+        s[6] += ratio < 1.25f ? 1.0 : 0.0;
+        s[7] += ratio < 1.25f * 1.25f ? 1.0 : 0.0;
+        s[8] += ratio < 1.25f * 1.25f * 1.25f ? 1.0 : 0.0;
+        s[9] += 1.0;
+    }
+    // wave64 shuffle reduction, then one atomic per wave
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        double v = s[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(acc + k, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: plan selection and launches
+// ------------------------------------------------------------------------------------------------
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up4(int a) { return (a + 3) & ~3; }
+inline size_t esize(int dt) { return dt == CSPN_F16 ? 2 : 4; }
+
+int grid_for(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+struct Launch {
+    PropArgs a;
+    int grid, threads, nq;
+    size_t lds_bytes;
+};
+
+// Geometry of one fused launch.  Returns false if (plan, S) does not fit the machine limits.
+bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, int threads, Launch* L) {
+    const int R = K / 2;
+    if (tw <= 0 || th <= 0 || (tw & 3) || nq <= 0) return false;
+    PropArgs& a = L->a;
+    a.B = B; a.H = H; a.W = W; a.S = S;
+    a.tw = tw; a.th = th;
+    a.tiles_x = ceil_div(W, tw);
+    a.tiles_y = ceil_div(H, th);
+    a.hyw = (S - 1) * R;
+    a.hxw = round_up4((S - 1) * R);
+    a.wq = (tw + 2 * a.hxw) / 4;
+    a.wr = th + 2 * a.hyw;
+    a.dr = a.wr + 2 * R;
+    a.ls = 4 * a.wq + 8;
+    if ((long)a.wq * ceil_div(a.wr, nq) > threads) return false;
+    L->lds_bytes = (size_t)2 * a.dr * a.ls * sizeof(float);
+    if (L->lds_bytes > 160 * 1024) return false;
+    L->grid = B * a.tiles_x * a.tiles_y;
+    L->threads = threads;
+    L->nq = nq;
+    return true;
+}
+
+// Built-in plan heuristic (overridable through cspn_plan): see DESIGN.md "plan selection".
+void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan* p) {
+    (void)B; (void)H; (void)T; (void)keep_history;
+    p->threads = 256;
+    p->force_scalar = 0;
+    p->steps_per_launch = 1;
+    p->tile_w = W >= 64 ? 64 : round_up4(W);
+    if (K == 3) { p->quads_per_thread = 2; }
+    else if (K == 5) { p->quads_per_thread = 1; }
+    else { p->quads_per_thread = 1; }
+    const int wq = p->tile_w / 4;
+    p->tile_h = (p->threads / wq) * p->quads_per_thread;
+}
+
+void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {
+    default_plan(K, B, H, W, T, keep_history, p);
+    if (user) {
+        if (user->steps_per_launch > 0) p->steps_per_launch = user->steps_per_launch;
+        if (user->tile_w > 0) p->tile_w = user->tile_w;
+        if (user->tile_h > 0) p->tile_h = user->tile_h;
+        if (user->quads_per_thread > 0) p->quads_per_thread = user->quads_per_thread;
+        if (user->threads > 0) p->threads = user->threads;
+        p->force_scalar = user->force_scalar;
+    }
+    if (W % 4 != 0) p->force_scalar = 1;
+    if (p->force_scalar) p->steps_per_launch = 1;
+    if (p->steps_per_launch > T && T > 0) p->steps_per_launch = T;
+    // do not own rows far below the image
+    const int nq = p->quads_per_thread;
+    const int hmax = ceil_div(H, nq) * nq;
+    if (p->tile_h > hmax) p->tile_h = hmax;
+}
+
+template <int K, int NQ, int NTHREADS, typename WT, typename DT>
+int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
+#define CSPN_LAUNCH(BL)                                                                               \
+    do {                                                                                              \
+        auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL>;                                     \
+        if (L.lds_bytes > 64 * 1024)                                                                  \
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes)); \
+        hipLaunchKernelGGL(kern, dim3(L.grid), dim3(NTHREADS), L.lds_bytes, st, L.a);                 \
+    } while (0)
+    switch (blend) {
+        case CSPN_BLEND_NONE: CSPN_LAUNCH(CSPN_BLEND_NONE); break;
+        case CSPN_BLEND_SPARSE: CSPN_LAUNCH(CSPN_BLEND_SPARSE); break;
+        case CSPN_BLEND_PREMASK: CSPN_LAUNCH(CSPN_BLEND_PREMASK); break;
+        default: return fail("bad blend mode %d", blend);
+    }
+#undef CSPN_LAUNCH
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+template <int K, typename WT, typename DT>
+int launch_fused(const Launch& L, int blend, hipStream_t st) {
+#define CSPN_CASE(NQV, NTV) \
+    if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT>(L, blend, st)
+    if constexpr (K == 3) {
+        CSPN_CASE(1, 256); CSPN_CASE(2, 256); CSPN_CASE(4, 256); CSPN_CASE(8, 256);
+        CSPN_CASE(2, 512); CSPN_CASE(4, 512);
+    } else if constexpr (K == 5) {
+        CSPN_CASE(1, 256); CSPN_CASE(2, 256); CSPN_CASE(3, 256); CSPN_CASE(1, 512);
+    } else {
+        CSPN_CASE(1, 256);
+    }
+#undef CSPN_CASE
+    return fail("no kernel instance for K=%d quads_per_thread=%d threads=%d", K, L.nq, L.threads);
+}
+
+template <int K, typename WT, typename DT>
+int launch_scalar(const void* w, const void* din, void* dout, const void* sp, const void* d0, int B, int H,
+                  int W, int blend, hipStream_t st) {
+    const int grid = grid_for((size_t)B * H * W, 256);
+    switch (blend) {
+        case CSPN_BLEND_NONE:
+            hipLaunchKernelGGL((cspn_prop_scalar<K, WT, DT, CSPN_BLEND_NONE>), dim3(grid), dim3(256), 0, st, w, din, dout, sp, d0, B, H, W);
+            break;
+        case CSPN_BLEND_SPARSE:
+            hipLaunchKernelGGL((cspn_prop_scalar<K, WT, DT, CSPN_BLEND_SPARSE>), dim3(grid), dim3(256), 0, st, w, din, dout, sp, d0, B, H, W);
+            break;
+        case CSPN_BLEND_PREMASK:
+            hipLaunchKernelGGL((cspn_prop_scalar<K, WT, DT, CSPN_BLEND_PREMASK>), dim3(grid), dim3(256), 0, st, w, din, dout, sp, d0, B, H, W);
+            break;
+        default: return fail("bad blend mode %d", blend);
+    }
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int K, typename WT, typename DT>
+int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
+                    int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st) {
+    const size_t plane_bytes = (size_t)B * H * W * sizeof(DT);
+    if (T == 0) {
+        if (out) HIP_OK(hipMemcpyAsync(out, d0, plane_bytes, hipMemcpyDeviceToDevice, st));
+        return 1;
+    }
+    cspn_plan p;
+    resolve_plan(K, B, H, W, T, history != nullptr, user, &p);
+    // the vector kernel needs whole, 16-byte (8-byte for f16) aligned quads
+    bool vec = !p.force_scalar && (W % 4 == 0) && aligned16(w) && aligned16(d0) && (!out || aligned16(out)) &&
+               (!history || aligned16(history)) && (!work || aligned16(work)) && (!sparse || aligned16(sparse));
+    if (p.steps_per_launch > 1 && !vec) p.steps_per_launch = 1;
+
+    // destination chain: d0 -> (work0 <-> work1)* -> out,  or history planes
+    char* wk = static_cast<char*>(work);
+    const void* src = d0;
+    int t = 0, launch_idx = 0;
+    const int n_launch = vec ? ceil_div(T, p.steps_per_launch) : T;
+    if (!history && n_launch > 1 && !work) return fail("workspace required (T=%d, launches=%d)", T, n_launch);
+    if (!history && !out) return fail("out is NULL and no history requested");
+    while (t < T) {
+        const int S = vec ? (T - t < p.steps_per_launch ? T - t : p.steps_per_launch) : 1;
+        void* dst;
+        void* hist_base = nullptr;
+        if (history) {
+            hist_base = static_cast<char*>(history) + (size_t)t * plane_bytes;
+            dst = static_cast<char*>(history) + (size_t)(t + S - 1) * plane_bytes;
+        } else {
+            dst = (t + S >= T) ? out : static_cast<void*>(wk + (size_t)(launch_idx & 1) * plane_bytes);
+        }
+        if (vec) {
+            Launch L;
+            if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, &L))
+                return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
+                            p.quads_per_thread, p.threads);
+            L.a.w = w; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
+            L.a.d_out = history ? nullptr : dst;
+            L.a.hist = hist_base;
+            if (!launch_fused<K, WT, DT>(L, blend, st)) return 0;
+        } else {
+            if (!launch_scalar<K, WT, DT>(w, src, dst, sparse, d0, B, H, W, blend, st)) return 0;
+        }
+        src = dst;
+        t += S;
+        ++launch_idx;
+    }
+    return 1;
+}
+
+template <int K>
+int propagate_k(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* history,
+                void* work, int d_dtype, int B, int H, int W, int T, int blend, const cspn_plan* plan,
+                hipStream_t st) {
+    if (w_dtype == CSPN_F32 && d_dtype == CSPN_F32)
+        return propagate_typed<K, float, float>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st);
+    if (w_dtype == CSPN_F16 && d_dtype == CSPN_F16)
+        return propagate_typed<K, __half, __half>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st);
+    if (w_dtype == CSPN_F16 && d_dtype == CSPN_F32)
+        return propagate_typed<K, __half, float>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st);
+    return fail("unsupported dtype combination w=%d d=%d", w_dtype, d_dtype);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int cspn_abi_version(void) { return CSPN_ABI_VERSION; }
+
+int cspn_plan_resolve(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* plan_or_null,
+                      cspn_plan* resolved) {
+    if (!resolved) return fail("cspn_plan_resolve: NULL output");
+    if (K != 3 && K != 5 && K != 7) return fail("cspn_plan_resolve: unsupported K=%d", K);
+    resolve_plan(K, B, H, W, T, keep_history, plan_or_null, resolved);
+    if (!resolved->force_scalar) {
+        Launch L;
+        if (!make_geometry(K, B, H, W, resolved->steps_per_launch, resolved->tile_w, resolved->tile_h,
+                           resolved->quads_per_thread, resolved->threads, &L))
+            return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, resolved->steps_per_launch,
+                        resolved->tile_w, resolved->tile_h, resolved->quads_per_thread, resolved->threads);
+    }
+    return 1;
+}
+const char* cspn_last_error(void) { return g_err; }
+
+int cspn3_prepare(const void* guidance, int g_dtype, long bs, long cs, int B, int H, int W, void* w8,
+                  int w_dtype, float* s_or_null, cspn_stream_t stream) {
+    if (!guidance || !w8 || B <= 0 || H <= 0 || W <= 0) return fail("cspn3_prepare: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+    if (g_dtype == CSPN_F32 && w_dtype == CSPN_F32)
+        hipLaunchKernelGGL((cspn3_prepare_kernel<float, float>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const float*>(guidance), bs, cs, B, H, W, static_cast<float*>(w8), s_or_null);
+    else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F16)
+        hipLaunchKernelGGL((cspn3_prepare_kernel<__half, __half>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const __half*>(guidance), bs, cs, B, H, W, static_cast<__half*>(w8), s_or_null);
+    else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F32)
+        hipLaunchKernelGGL((cspn3_prepare_kernel<__half, float>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const __half*>(guidance), bs, cs, B, H, W, static_cast<float*>(w8), s_or_null);
+    else
+        return fail("cspn3_prepare: unsupported dtypes g=%d w=%d", g_dtype, w_dtype);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int cspn_pac_prepare(const void* guided, int g_dtype, int B, int H, int W, int K, void* wk, int w_dtype,
+                     cspn_stream_t stream) {
+    if (!guided || !wk || B <= 0 || H <= 0 || W <= 0) return fail("cspn_pac_prepare: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+#define PAC_PREP(KV)                                                                                           \
+    if (K == KV) {                                                                                             \
+        if (g_dtype == CSPN_F32 && w_dtype == CSPN_F32)                                                        \
+            hipLaunchKernelGGL((cspn_pac_prepare_kernel<KV, float, float>), dim3(grid), dim3(256), 0, st,      \
+                               static_cast<const float*>(guided), B, H, W, static_cast<float*>(wk));           \
+        else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F16)                                                   \
+            hipLaunchKernelGGL((cspn_pac_prepare_kernel<KV, __half, __half>), dim3(grid), dim3(256), 0, st,    \
+                               static_cast<const __half*>(guided), B, H, W, static_cast<__half*>(wk));         \
+        else                                                                                                   \
+            return fail("cspn_pac_prepare: unsupported dtypes g=%d w=%d", g_dtype, w_dtype);                   \
+        HIP_OK(hipGetLastError());                                                                             \
+        return 1;                                                                                              \
+    }
+    PAC_PREP(3) PAC_PREP(5) PAC_PREP(7)
+#undef PAC_PREP
+    return fail("cspn_pac_prepare: unsupported K=%d (3, 5, 7)", K);
+}
+
+size_t cspn_propagate_workspace_bytes(int B, int H, int W, int T, int d_dtype, int keep_history) {
+    if (keep_history || T <= 1) return 0;
+    return (size_t)2 * B * H * W * esize(d_dtype);
+}
+
+int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* history,
+                   void* work, int d_dtype, int B, int H, int W, int K, int T, int blend, const cspn_plan* plan,
+                   cspn_stream_t stream) {
+    if (!w || !d0 || B <= 0 || H <= 0 || W <= 0 || T < 0) return fail("cspn_propagate: bad arguments");
+    if (blend != CSPN_BLEND_NONE && !sparse) return fail("cspn_propagate: blend=%d needs sparse", blend);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (K) {
+        case 3: return propagate_k<3>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
+        case 5: return propagate_k<5>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
+        case 7: return propagate_k<7>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
+        default: return fail("cspn_propagate: unsupported K=%d (3, 5, 7)", K);
+    }
+}
+
+int cspn_transpose_weights(const void* w, void* wT, int w_dtype, int B, int H, int W, int K, cspn_stream_t stream) {
+    if (!w || !wT) return fail("cspn_transpose_weights: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+#define TR(KV)                                                                                              \
+    if (K == KV) {                                                                                          \
+        if (w_dtype == CSPN_F32)                                                                            \
+            hipLaunchKernelGGL((cspn_transpose_kernel<KV, float>), dim3(grid), dim3(256), 0, st,            \
+                               static_cast<const float*>(w), static_cast<float*>(wT), B, H, W);             \
+        else                                                                                                \
+            hipLaunchKernelGGL((cspn_transpose_kernel<KV, __half>), dim3(grid), dim3(256), 0, st,           \
+                               static_cast<const __half*>(w), static_cast<__half*>(wT), B, H, W);           \
+        HIP_OK(hipGetLastError());                                                                          \
+        return 1;                                                                                           \
+    }
+    TR(3) TR(5) TR(7)
+#undef TR
+    return fail("cspn_transpose_weights: unsupported K=%d", K);
+}
+
+int cspn_grad_weights(const void* d0, const void* dhist, const float* ghist, const void* sparse, float* gw,
+                      float* gd0, int d_dtype, int B, int H, int W, int K, int T, cspn_stream_t stream) {
+    if (!d0 || !ghist || !gw || !gd0 || (T > 1 && !dhist)) return fail("cspn_grad_weights: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+#define GWK(KV)                                                                                                \
+    if (K == KV) {                                                                                             \
+        if (d_dtype == CSPN_F32)                                                                               \
+            hipLaunchKernelGGL((cspn_grad_weights_kernel<KV, float>), dim3(grid), dim3(256), 0, st,            \
+                               static_cast<const float*>(d0), static_cast<const float*>(dhist), ghist,         \
+                               static_cast<const float*>(sparse), gw, gd0, B, H, W, T);                        \
+        else                                                                                                   \
+            hipLaunchKernelGGL((cspn_grad_weights_kernel<KV, __half>), dim3(grid), dim3(256), 0, st,           \
+                               static_cast<const __half*>(d0), static_cast<const __half*>(dhist), ghist,       \
+                               static_cast<const __half*>(sparse), gw, gd0, B, H, W, T);                       \
+        HIP_OK(hipGetLastError());                                                                             \
+        return 1;                                                                                              \
+    }
+    GWK(3) GWK(5) GWK(7)
+#undef GWK
+    return fail("cspn_grad_weights: unsupported K=%d", K);
+}
+
+int cspn3_grad_guidance(const void* guidance, int g_dtype, long bs, long cs, int C, const void* w8, int w_dtype,
+                        const float* s, const float* gw, void* grad_guidance, int B, int H, int W,
+                        cspn_stream_t stream) {
+    if (!guidance || !w8 || !s || !gw || !grad_guidance) return fail("cspn3_grad_guidance: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+    if (g_dtype == CSPN_F32 && w_dtype == CSPN_F32)
+        hipLaunchKernelGGL((cspn3_grad_guidance_kernel<float, float>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const float*>(guidance), bs, cs, C, static_cast<const float*>(w8), s, gw,
+                           static_cast<float*>(grad_guidance), B, H, W);
+    else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F16)
+        hipLaunchKernelGGL((cspn3_grad_guidance_kernel<__half, __half>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const __half*>(guidance), bs, cs, C, static_cast<const __half*>(w8), s, gw,
+                           static_cast<__half*>(grad_guidance), B, H, W);
+    else
+        return fail("cspn3_grad_guidance: unsupported dtypes g=%d w=%d", g_dtype, w_dtype);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* grad_guided, int g_dtype, int B,
+                         int H, int W, int K, cspn_stream_t stream) {
+    if (!wk || !gw || !grad_guided) return fail("cspn_pac_grad_guided: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+#define PG(KV)                                                                                                 \
+    if (K == KV) {                                                                                             \
+        if (w_dtype == CSPN_F32 && g_dtype == CSPN_F32)                                                        \
+            hipLaunchKernelGGL((cspn_pac_grad_guided_kernel<KV, float, float>), dim3(grid), dim3(256), 0, st,  \
+                               static_cast<const float*>(wk), gw, static_cast<float*>(grad_guided), B, H, W);  \
+        else if (w_dtype == CSPN_F16 && g_dtype == CSPN_F16)                                                   \
+            hipLaunchKernelGGL((cspn_pac_grad_guided_kernel<KV, __half, __half>), dim3(grid), dim3(256), 0, st,\
+                               static_cast<const __half*>(wk), gw, static_cast<__half*>(grad_guided), B, H, W);\
+        else                                                                                                   \
+            return fail("cspn_pac_grad_guided: unsupported dtypes");                                           \
+        HIP_OK(hipGetLastError());                                                                             \
+        return 1;                                                                                              \
+    }
+    PG(3) PG(5) PG(7)
+#undef PG
+    return fail("cspn_pac_grad_guided: unsupported K=%d", K);
+}
+
+int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, size_t n, double* acc10,
+                            cspn_stream_t stream) {
+    if (!pred || !target || !acc10) return fail("cspn_metrics_accumulate: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n, 256) > 1024 ? 1024 : grid_for(n, 256);
+    if (dtype == CSPN_F32)
+        hipLaunchKernelGGL((cspn_metrics_kernel<float>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const float*>(pred), static_cast<const float*>(target), n, acc10);
+    else if (dtype == CSPN_F16)
+        hipLaunchKernelGGL((cspn_metrics_kernel<__half>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const __half*>(pred), static_cast<const __half*>(target), n, acc10);
+    else
+        return fail("cspn_metrics_accumulate: unsupported dtype %d", dtype);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+"""Depth metrics on device + the batch-shard / metrics all-gather used for multi-GPU inference.
+
+Reference formulas: libs/metrics.py:49-83 (Result.evaluate) and the on-device twin
+network/libs/base/base_model.py:28-73, whose 10-vector order (irmse, imae, mse, rmse, mae, absrel,
+lg10, delta1, delta2, delta3) is kept.  The reference averages the per-GPU vectors with an
+in-process Reduce (network/libs/base/encoding.py:264-276), which is only right for equal valid-pixel
+counts; here every rank contributes additive masked *sums* + the count, gathered with one
+torch.distributed all_gather (RCCL over xGMI when the backend is "nccl"), then finalised.
+"""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+METRIC_NAMES = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
+N_SUMS = 10   # {inv^2, inv, diff^2, diff, diff/t, |dlog10|, #<1.25, #<1.25^2, #<1.25^3, n}
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous batch chunks: rank r gets [lo, hi); remainders go to the low ranks."""
+    base, rem = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def metric_sums(pred, target, out=None):
+    """Masked sums over target > 0 as a float64[10] device tensor (one fused HIP reduction kernel).
+
+    `out` (float64[10]) is accumulated into when given, so a loop over batches needs no host sync."""
+    if not (pred.is_cuda and target.is_cuda):
+        raise RuntimeError("metric_sums: tensors must live on a ROCm device (no CPU implementation here)")
+    if pred.shape != target.shape or pred.dtype != target.dtype:
+        raise ValueError("pred / target must have the same shape and dtype")
+    p, t = pred.contiguous(), target.contiguous()
+    acc = torch.zeros(N_SUMS, dtype=torch.float64, device=p.device) if out is None else out
+    dt = _lib.CSPN_F32 if p.dtype == torch.float32 else _lib.CSPN_F16 if p.dtype == torch.float16 else None
+    if dt is None:
+        raise TypeError("metric_sums supports float32 / float16")
+    with torch.cuda.device(p.device):
+        ok = _lib.lib().cspn_metrics_accumulate(
+            ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(t.data_ptr()), dt, p.numel(),
+            ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+    _lib.check(ok, "cspn_metrics_accumulate")
+    return acc
+
+
+def finalize_metrics(sums):
+    """float64[10] sums -> dict of the reference's 10 metrics + 'count'."""
+    s = [float(v) for v in sums]
+    n = s[9]
+    if n <= 0:
+        return dict({k: float("nan") for k in METRIC_NAMES}, count=0)
+    mse = s[2] / n
+    return dict(irmse=math.sqrt(s[0] / n), imae=s[1] / n, mse=mse, rmse=math.sqrt(mse), mae=s[3] / n,
+                absrel=s[4] / n, lg10=s[5] / n, delta1=s[6] / n, delta2=s[7] / n, delta3=s[8] / n,
+                count=int(round(n)))
+
+
+def all_gather_metric_sums(sums, group=None):
+    """All-gather the per-rank sums (world x 10 float64) and add them.  Works with gloo (CPU) and nccl/RCCL."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums.clone(), sums.unsqueeze(0).clone()
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(sums) for _ in range(world)]
+    dist.all_gather(parts, sums.contiguous(), group=group)
+    stacked = torch.stack(parts, 0)
+    return stacked.sum(0), stacked

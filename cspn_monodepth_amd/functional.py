@@ -1,0 +1,303 @@
+"""Tensor-level host API over the C ABI (include/cspn_hip.h): validation, buffer ownership, autograd.
+
+Mirrors the calling discipline of the reference's native wrappers (network/libs/inplace_abn/
+functions.py:13-16 `_check`, :65-67 contiguity checks, lib_cffi.cpp:37 current stream): PyTorch owns
+every buffer, the engine enqueues on the tensor's current HIP stream, failures raise RuntimeError.
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic of the hot
+path runs in libcspn_hip.so.  There is no CPU fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import BLEND_NONE, BLEND_PREMASK, BLEND_SPARSE, CSPN_F16, CSPN_F32, cspn_plan
+
+_DEFAULT_PLANS = {}   # K -> dict, set by set_default_plan (e.g. from a tuning run)
+_EVENT_LOG = None     # when a list: propagate() appends (start_event, end_event, n_launches, steps_per_launch)
+
+
+def set_event_log(log):
+    """bench.py hook: HIP events recorded on the launch stream around every propagation loop."""
+    global _EVENT_LOG
+    _EVENT_LOG = log
+
+
+def resolve_plan(K, B, H, W, T, keep_history=False, plan=None):
+    """The plan the engine will actually use (dict), via cspn_plan_resolve."""
+    out = cspn_plan()
+    ok = _lib.lib().cspn_plan_resolve(int(K), int(B), int(H), int(W), int(T), int(bool(keep_history)),
+                                      _plan_ptr(K, plan), ctypes.byref(out))
+    _lib.check(ok, "cspn_plan_resolve")
+    return {name: int(getattr(out, name)) for name, _ in cspn_plan._fields_}
+
+
+def set_default_plan(K, plan):
+    """plan: None or dict(steps_per_launch=, tile_w=, tile_h=, quads_per_thread=, threads=, force_scalar=)."""
+    if plan is None:
+        _DEFAULT_PLANS.pop(int(K), None)
+    else:
+        _DEFAULT_PLANS[int(K)] = dict(plan)
+
+
+def _plan_ptr(K, plan):
+    plan = _DEFAULT_PLANS.get(int(K)) if plan is None else plan
+    if plan is None:
+        return None
+    if isinstance(plan, cspn_plan):
+        return ctypes.pointer(plan)
+    p = cspn_plan()
+    for k, v in plan.items():
+        if not hasattr(p, k):
+            raise ValueError("unknown plan field %r" % k)
+        setattr(p, k, int(v))
+    return ctypes.pointer(p)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return CSPN_F32
+    if t.dtype == torch.float16:
+        return CSPN_F16
+    raise TypeError("CSPN HIP engine supports float32 / float16 tensors, got %s" % t.dtype)
+
+
+def _require_device(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("CSPN HIP engine: tensors must live on a ROCm device (got %s); "
+                               "there is no CPU implementation in this package" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("CSPN HIP engine: tensors on different devices (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _plane(t, B, H, W, name):
+    """[B,1,H,W] / [B,H,W] -> contiguous; returns tensor viewed as [B,H,W]."""
+    if t is None:
+        return None
+    if t.dim() == 4:
+        if t.shape[1] != 1:
+            raise ValueError("%s must have exactly one channel, got shape %s" % (name, tuple(t.shape)))
+        t = t[:, 0]
+    if tuple(t.shape) != (B, H, W):
+        raise ValueError("%s has shape %s, expected [%d,1,%d,%d]" % (name, tuple(t.shape), B, H, W))
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ raw ops
+def cspn3_prepare(guidance, want_s=False, w_dtype=None):
+    """|g| -> shift -> /S: the 8 normalised weight planes of the 3x3 variant (CSPN_new.py:29-70,:124-127).
+
+    Reads channels 0..7 of a [B,C>=8,H,W] guidance in place (C=12 from unet_cspn_nyu.py:332)."""
+    dev = _require_device(guidance)
+    if guidance.dim() != 4 or guidance.shape[1] < 8:
+        raise ValueError("guidance must be [B,C>=8,H,W], got %s" % (tuple(guidance.shape),))
+    B, C, H, W = guidance.shape
+    g = guidance if guidance.is_contiguous() else guidance.contiguous()
+    w_dtype = g.dtype if w_dtype is None else w_dtype
+    w8 = torch.empty((B, 8, H, W), dtype=w_dtype, device=dev)
+    S = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_s else None
+    with torch.cuda.device(dev):
+        ok = _lib.lib().cspn3_prepare(_p(g), _dt(g), g.stride(0), g.stride(1), B, H, W, _p(w8), _dt(w8), _p(S),
+                                      _stream(dev))
+    _lib.check(ok, "cspn3_prepare")
+    return w8, S, g
+
+
+def pac_prepare(guided, w_dtype=None):
+    """softmax over the K^2-1 taps at the centre pixel (CSPN_ours.py:35-41; the centre tap is implicit)."""
+    dev = _require_device(guided)
+    if guided.dim() != 4:
+        raise ValueError("guided must be [B,K*K-1,H,W]")
+    B, C, H, W = guided.shape
+    K = int(math.sqrt(C + 1))                      # CSPN_ours.py:32
+    if K * K != C + 1 or K not in (3, 5, 7):
+        raise ValueError("guided has %d channels; supported K*K-1 for K in (3,5,7)" % C)
+    g = guided.contiguous()
+    w_dtype = g.dtype if w_dtype is None else w_dtype
+    if w_dtype != g.dtype:
+        raise TypeError("pac_prepare: weight dtype must equal guided dtype")
+    wk = torch.empty((B, C, H, W), dtype=w_dtype, device=dev)
+    with torch.cuda.device(dev):
+        ok = _lib.lib().cspn_pac_prepare(_p(g), _dt(g), B, H, W, K, _p(wk), _dt(wk), _stream(dev))
+    _lib.check(ok, "cspn_pac_prepare")
+    return wk, K
+
+
+def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
+    """T steps of d <- blend(sum_j w_j * d[.+off_j]).  w [B,K*K-1,H,W]; d0, sparse [B,H,W].
+
+    Returns (d_T [B,H,W], history [T,B,H,W] or None); with history, d_T is history[T-1] (a view)."""
+    dev = _require_device(w, d0, sparse)
+    B, NT, H, W = w.shape
+    if NT != K * K - 1:
+        raise ValueError("weight volume has %d planes, expected %d" % (NT, K * K - 1))
+    if not (w.is_contiguous() and d0.is_contiguous() and (sparse is None or sparse.is_contiguous())):
+        raise ValueError("propagate: tensors must be contiguous")
+    if sparse is not None and sparse.dtype != d0.dtype:
+        raise TypeError("sparse dtype must equal the depth dtype")
+    if blend != BLEND_NONE and sparse is None:
+        raise ValueError("blend mode needs sparse")
+    L = _lib.lib()
+    hist = out = work = None
+    T = int(T)
+    if keep_history and T > 0:
+        hist = torch.empty((T, B, H, W), dtype=d0.dtype, device=dev)
+    else:
+        out = torch.empty((B, H, W), dtype=d0.dtype, device=dev)
+        nbytes = L.cspn_propagate_workspace_bytes(B, H, W, T, _dt(d0), 0)
+        if nbytes:
+            work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    log = _EVENT_LOG
+    with torch.cuda.device(dev):
+        if log is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(dev))
+        ok = L.cspn_propagate(_p(w), _dt(w), _p(d0), _p(sparse), _p(out), _p(hist), _p(work), _dt(d0),
+                              B, H, W, int(K), T, int(blend), _plan_ptr(K, plan), _stream(dev))
+        if log is not None:
+            ev1.record(torch.cuda.current_stream(dev))
+            S = resolve_plan(K, B, H, W, T, keep_history, plan)["steps_per_launch"]
+            log.append((ev0, ev1, -(-T // max(S, 1)), S))
+    _lib.check(ok, "cspn_propagate")
+    if hist is not None:
+        return hist[T - 1], hist
+    return out, None
+
+
+def transpose_weights(w, K):
+    dev = _require_device(w)
+    B, NT, H, W = w.shape
+    wT = torch.empty_like(w)
+    with torch.cuda.device(dev):
+        ok = _lib.lib().cspn_transpose_weights(_p(w), _p(wT), _dt(w), B, H, W, int(K), _stream(dev))
+    _lib.check(ok, "cspn_transpose_weights")
+    return wT
+
+
+def _backward_common(w, K, T, d0, dhist, sparse, grad_out, plan):
+    """Shared reverse sweep: returns (gw [B,NT,H,W] f32, gd0 [B,H,W] f32)."""
+    dev = w.device
+    B, NT, H, W = w.shape
+    L = _lib.lib()
+    ghist = torch.empty((T + 1, B, H, W), dtype=torch.float32, device=dev)
+    ghist[0].copy_(grad_out.reshape(B, H, W))
+    sp32 = None if sparse is None else sparse.float()
+    if T > 0:
+        wT = transpose_weights(w, K)
+        with torch.cuda.device(dev):
+            ok = L.cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None, CSPN_F32,
+                                  B, H, W, int(K), T, BLEND_PREMASK if sparse is not None else BLEND_NONE,
+                                  _plan_ptr(K, plan), _stream(dev))
+        _lib.check(ok, "cspn_propagate(backward)")
+    gw = torch.empty((B, NT, H, W), dtype=torch.float32, device=dev)
+    gd0 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ok = L.cspn_grad_weights(_p(d0), _p(dhist), _p(ghist), _p(sparse), _p(gw), _p(gd0), _dt(d0),
+                                 B, H, W, int(K), T, _stream(dev))
+    _lib.check(ok, "cspn_grad_weights")
+    return gw, gd0
+
+
+# ------------------------------------------------------------------------------------------------ autograd
+class CSPN3Function(torch.autograd.Function):
+    """3x3 variant, forward + hand-written backward (SURVEY.md §3.2 closed form)."""
+
+    @staticmethod
+    def forward(ctx, guidance, blur_depth, sparse_depth, prop_time, plan):
+        B, C, H, W = guidance.shape
+        d0 = _plane(blur_depth, B, H, W, "blur_depth")
+        sp = _plane(sparse_depth, B, H, W, "sparse_depth")
+        if d0.dtype != guidance.dtype or (sp is not None and sp.dtype != guidance.dtype):
+            raise TypeError("guidance / blur_depth / sparse_depth must share one dtype")
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        w8, S, g = cspn3_prepare(guidance, want_s=need_grad)
+        out, hist = propagate(w8, d0, sp, 3, prop_time, BLEND_SPARSE if sp is not None else BLEND_NONE,
+                              keep_history=need_grad, plan=plan)
+        if need_grad:
+            ctx.save_for_backward(g, w8, S, d0, sp, hist)
+            ctx.prop_time, ctx.plan = int(prop_time), plan
+            ctx.in_shape = tuple(blur_depth.shape)
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g, w8, S, d0, sp, hist = ctx.saved_tensors
+        B, C, H, W = g.shape
+        T = ctx.prop_time
+        go = grad_out.contiguous().float()
+        gw, gd0 = _backward_common(w8, 3, T, d0, hist, sp, go, ctx.plan)
+        gg = None
+        if ctx.needs_input_grad[0]:
+            gg = torch.empty_like(g)
+            with torch.cuda.device(g.device):
+                ok = _lib.lib().cspn3_grad_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), C, _p(w8), _dt(w8),
+                                                    _p(S), _p(gw), _p(gg), B, H, W, _stream(g.device))
+            _lib.check(ok, "cspn3_grad_guidance")
+        gd = gd0.to(d0.dtype).reshape(ctx.in_shape) if ctx.needs_input_grad[1] else None
+        return gg, gd, None, None, None
+
+
+class PACFunction(torch.autograd.Function):
+    """K x K softmax variant (CSPN_ours.py / pac.py) forward + backward."""
+
+    @staticmethod
+    def forward(ctx, x, guided, sparse_depth, prop_time, plan, state_dtype):
+        B, C, H, W = guided.shape
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError("x must be [B,1,H,W] (the depth map); got %s" % (tuple(x.shape),))
+        wk, K = pac_prepare(guided)
+        sdt = x.dtype if state_dtype is None else state_dtype
+        d0 = _plane(x, B, H, W, "x").to(sdt)
+        sp = _plane(sparse_depth, B, H, W, "sparse_depth")
+        sp = None if sp is None else sp.to(sdt)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        out, hist = propagate(wk, d0, sp, K, prop_time, BLEND_SPARSE if sp is not None else BLEND_NONE,
+                              keep_history=need_grad, plan=plan)
+        if need_grad:
+            ctx.save_for_backward(wk, d0, sp, hist)
+            ctx.K, ctx.prop_time, ctx.plan = K, int(prop_time), plan
+            ctx.x_dtype, ctx.g_dtype = x.dtype, guided.dtype
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        wk, d0, sp, hist = ctx.saved_tensors
+        B, NT, H, W = wk.shape
+        gw, gx0 = _backward_common(wk, ctx.K, ctx.prop_time, d0, hist, sp, grad_out.contiguous().float(), ctx.plan)
+        gg = None
+        if ctx.needs_input_grad[1]:
+            gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
+            with torch.cuda.device(wk.device):
+                ok = _lib.lib().cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, ctx.K,
+                                                     _stream(wk.device))
+            _lib.check(ok, "cspn_pac_grad_guided")
+        gx = gx0.to(ctx.x_dtype).unsqueeze(1) if ctx.needs_input_grad[0] else None
+        return gx, gg, None, None, None, None
+
+
+def cspn3_affinity_propagate(guidance, blur_depth, sparse_depth=None, prop_time=24, plan=None):
+    """Functional form of CSPN_new.AffinityPropagate.forward (CSPN_new.py:26-92)."""
+    _require_device(guidance, blur_depth, sparse_depth)
+    return CSPN3Function.apply(guidance, blur_depth, sparse_depth, int(prop_time), plan)
+
+
+def pac_affinity_propagate(x, guided, sparse_depth=None, prop_time=24, plan=None, state_dtype=None):
+    """Functional form of CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54)."""
+    _require_device(x, guided, sparse_depth)
+    return PACFunction.apply(x, guided, sparse_depth, int(prop_time), plan, state_dtype)

@@ -1,0 +1,135 @@
+/*
+ * cspn_hip.h — C ABI of libcspn_hip.so, the MI355X (gfx950) CSPN affinity-propagation engine.
+ *
+ * This is the drop-in boundary for the reference's hot path (paths relative to the reference repo):
+ *   network/libs/post_process/CSPN_new.py:26-128   AffinityPropagate.forward (3x3, 24 steps)
+ *   network/libs/post_process/CSPN_ours.py:24-54   AffinityPropagate.forward (K x K softmax / PAC)
+ *   network/libs/base/pac.py:75-121                Conv2dFn.forward / backward
+ *
+ * Conventions (modelled on the reference's only native interface, In-Place ABN:
+ * network/libs/inplace_abn/src/bn.h:7-19, bn.cu:237-300, lib_cffi.cpp:1-2,36-63):
+ *   - every entry point returns 1 on success and 0 on failure (bn.cu:249 `return 1` after the
+ *     cudaGetLastError check); on failure cspn_last_error() returns a thread-local message;
+ *   - "all functions assume input and output tensors are already initialised and have the
+ *     correct dimensions" (lib_cffi.cpp:1-2): the caller validates shapes / contiguity;
+ *   - optional tensors are passed as NULL (lib_cffi.cpp:62-63 maps empty tensors to NULL);
+ *   - the caller owns every buffer (including workspace); the library never allocates,
+ *     frees or retains device pointers, enqueues on the given stream and does not synchronise;
+ *   - re-entrant: no global mutable state; the caller selects the device (hipSetDevice)
+ *     before the call, as `with torch.cuda.device(...)` does at encoding.py:168.
+ *
+ * Tensor layout: NCHW contiguous planes.  "taps" are the K*K-1 non-centre offsets (dy,dx) in
+ * row-major order over [-K/2, K/2]^2; tap plane j of a weight volume multiplies depth[p + off_j].
+ */
+#ifndef CSPN_HIP_H_
+#define CSPN_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSPN_ABI_VERSION 1
+
+typedef void* cspn_stream_t; /* hipStream_t */
+
+/* element types */
+enum { CSPN_F32 = 0, CSPN_F16 = 1 };
+
+/* blend modes of one propagation step */
+enum {
+    CSPN_BLEND_NONE = 0,   /* d' = u                                                            */
+    CSPN_BLEND_SPARSE = 1, /* d' = (1-m) u + m d0, m = sign(sparse)    CSPN_new.py:90, CSPN_ours.py:53 */
+    CSPN_BLEND_PREMASK = 2 /* u = stencil((1-m) d): transposed recurrence used by the backward pass */
+};
+
+/* Launch plan of the propagation loop.  All zero (or a NULL plan) = built-in heuristic. */
+typedef struct cspn_plan {
+    int steps_per_launch; /* S: propagation steps fused into one kernel launch (temporal blocking) */
+    int tile_w;           /* interior tile width in pixels, multiple of 4                          */
+    int tile_h;           /* interior tile height in pixels                                        */
+    int quads_per_thread; /* NQ: vertically consecutive 4-pixel groups owned by one thread         */
+    int threads;          /* workgroup size (256 / 512 / 1024)                                     */
+    int force_scalar;     /* 1 = use the generic per-pixel kernel (any W, any alignment)           */
+} cspn_plan;
+
+int cspn_abi_version(void);
+const char* cspn_last_error(void);
+
+/* Effective launch plan for a problem (defaults merged with `plan_or_null`, W%4 fallback applied) and a
+ * check that it fits the machine (threads, 160 KiB LDS).  Lets the host size its expectations (number of
+ * launches = ceil(T / steps_per_launch)) without duplicating the heuristic. */
+int cspn_plan_resolve(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* plan_or_null,
+                      cspn_plan* resolved);
+
+/* ---- 3x3, gate-at-the-neighbour, sum-normalised variant (CSPN_new.py) ------------------------ */
+
+/* w8[b][j][p] = |guidance[b][7-j][p+off_j]| / sum_k |guidance[b][k][p+o_k]|   (CSPN_new.py:29-70,:124-127)
+ * guidance is read through explicit batch / channel strides (in elements), so the first 8
+ * channels of the UNet's 12-channel head (unet_cspn_nyu.py:332) are used in place.
+ * w8: [B,8,H,W] of w_dtype.  s_or_null: optional [B,H,W] f32 receiving the normaliser S. */
+int cspn3_prepare(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
+                  int B, int H, int W, void* w8, int w_dtype, float* s_or_null, cspn_stream_t stream);
+
+/* ---- K x K, centre-indexed softmax variant (CSPN_ours.py + pac.py) -------------------------- */
+
+/* wk[b][j][p] = softmax_c(guided[b][:, p])[j]  for the K*K-1 taps (CSPN_ours.py:35-41). */
+int cspn_pac_prepare(const void* guided, int g_dtype, int B, int H, int W, int K,
+                     void* wk, int w_dtype, cspn_stream_t stream);
+
+/* ---- the propagation loop (both variants) ---------------------------------------------------- */
+
+/* Bytes of caller-provided workspace cspn_propagate needs (ping-pong planes; 0 when history is kept). */
+size_t cspn_propagate_workspace_bytes(int B, int H, int W, int T, int d_dtype, int keep_history);
+
+/* Runs T steps  d_{t+1}[p] = blend( sum_j w[j][p] * d_t[p+off_j] ).
+ *   w       [B,K*K-1,H,W] w_dtype      d0 [B,H,W] d_dtype      sparse (NULL unless blend != NONE)
+ *   out     [B,H,W] d_dtype; receives d_T.  Ignored (may be NULL) when history != NULL.
+ *   history NULL, or [T,B,H,W] d_dtype receiving d_1..d_T (d_T = history[T-1]) — what backward needs.
+ *   work    cspn_propagate_workspace_bytes() bytes, or NULL if that is 0.
+ * Replaces the 24x {8 pads, cat, mul, 2 conv3d, div, crop, blend} loop at CSPN_new.py:80-90 and the
+ * unfold/mul/einsum loop at CSPN_ours.py:47-53 / pac.py:89-92. */
+int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* sparse, void* out,
+                   void* history, void* work, int d_dtype, int B, int H, int W, int K, int T,
+                   int blend, const cspn_plan* plan, cspn_stream_t stream);
+
+/* ---- backward ---------------------------------------------------------------------------------- */
+
+/* wT[b][j][q] = w[b][NT-1-j][q+off_j] (0 outside): weights of the transposed stencil, so that the
+ * backward recurrence G_t = stencilT((1-m) G_{t+1}) runs through cspn_propagate(…, CSPN_BLEND_PREMASK). */
+int cspn_transpose_weights(const void* w, void* wT, int w_dtype, int B, int H, int W, int K,
+                           cspn_stream_t stream);
+
+/* gw[b][j][p] = (1-m[p]) * sum_{t=0}^{T-1} G_{t+1}[p] * d_t[p+off_j]      (dL/dw, f32)
+ * gd0[b][p]   = G_0[p] + m[p] * sum_{t=1}^{T} G_t[p]                       (dL/d coarse depth, f32)
+ *   d0 [B,H,W], dhist [T,B,H,W] = d_1..d_T (forward history; plane T-1 is not read),
+ *   ghist [T+1,B,H,W] in backward order: ghist[s] = G_{T-s}, i.e. ghist[0] = dL/dout and ghist[1..T] is
+ *   the history written by cspn_propagate(wT, d0 = ghist[0], ..., history = ghist + plane). */
+int cspn_grad_weights(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+                      float* gw, float* gd0, int d_dtype, int B, int H, int W, int K, int T,
+                      cspn_stream_t stream);
+
+/* 3x3 variant: dL/dguidance from dL/dw (quotient rule of w = A/S, un-shift, sign(guidance)):
+ *   gA_j = (gw_j - sum_k gw_k w_k) / S ;  dL/dg[b][7-j][q] = sign(g) * gA_j[q - off_j]
+ * grad_guidance uses the guidance strides; channels >= 8 are zero-filled (never read by the forward). */
+int cspn3_grad_guidance(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
+                        int C, const void* w8, int w_dtype, const float* s, const float* gw,
+                        void* grad_guidance, int B, int H, int W, cspn_stream_t stream);
+
+/* K x K variant: softmax backward  dL/dguided_c = sm_c (gw_c - sum_k gw_k sm_k). */
+int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* grad_guided, int g_dtype,
+                         int B, int H, int W, int K, cspn_stream_t stream);
+
+/* ---- evaluation (libs/metrics.py:49-83, base_model.py:28-73) ------------ */
+
+/* acc[0..9] (f64, zero-initialised by the caller) += masked sums over target>0 of
+ * {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), n};
+ * the host turns them into irmse, imae, mse, rmse, mae, absrel, lg10, delta1..3 (+ the count n). */
+int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, size_t n,
+                            double* acc10, cspn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSPN_HIP_H_ */

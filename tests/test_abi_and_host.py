@@ -1,0 +1,83 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol the header declares,
+the host-side mirror of the reference interface behaves like the reference's module API, and nothing
+in the product path can silently fall back to a CPU implementation."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import cspn_monodepth_amd as pkg
+from cspn_monodepth_amd import _lib
+from conftest import ROOT
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "cspn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cspn\w*)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    declared = _header_functions()
+    assert set(declared) == set(_lib.EXPORTS), (declared, _lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.lib().cspn_abi_version() == 1
+    assert _lib.lib().cspn_propagate_workspace_bytes(24, 228, 304, 24, _lib.CSPN_F32, 0) == 2 * 24 * 228 * 304 * 4
+    assert _lib.lib().cspn_propagate_workspace_bytes(24, 228, 304, 24, _lib.CSPN_F32, 1) == 0
+
+
+def test_module_api_matches_reference_contract():
+    m = pkg.CSPN_new.AffinityPropagate(24, 3)            # unet_cspn_nyu.py:357-358
+    assert (m.prop_time, m.prop_kernel, m.in_feature, m.out_feature) == (24, 3, 1, 1)
+    assert len(m.state_dict()) == 0 and len(list(m.parameters())) == 0
+    with pytest.raises(ValueError):
+        pkg.CSPN_new.AffinityPropagate(24, 5)
+    p = pkg.CSPN_ours.AffinityPropagate(prop_time=24)    # unet_ours.py:304-305
+    assert p.times == 24 and len(p.state_dict()) == 0
+    import inspect
+    assert list(inspect.signature(m.forward).parameters) == ["guidance", "blur_depth", "sparse_depth"]
+    assert list(inspect.signature(p.forward).parameters) == ["x", "guided", "sparse_depth"]
+
+
+def test_no_cpu_fallback():
+    m = pkg.CSPN_new.AffinityPropagate(24, 3)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        m(torch.randn(1, 8, 4, 4), torch.rand(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        pkg.CSPN_ours.AffinityPropagate(3)(torch.rand(1, 1, 4, 4), torch.randn(1, 8, 4, 4))
+    with pytest.raises(RuntimeError):
+        pkg.evaluation.metric_sums(torch.rand(4), torch.rand(4))
+    # the product package never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "cspn_monodepth_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_shard_bounds_and_finalize():
+    ev = pkg.evaluation
+    for n, w in ((24, 8), (8, 8), (24, 5), (3, 4)):
+        spans = [ev.shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    import numpy as np
+    from oracle import cspn_oracle as orc
+    from conftest import load_golden
+    z = load_golden("g7_metrics")
+    fin = ev.finalize_metrics(orc.metric_sums(z["pred"], z["target"]))
+    for k, v in zip(ev.METRIC_NAMES, z["metrics"]):
+        assert np.isclose(fin[k], v, rtol=2e-6), k

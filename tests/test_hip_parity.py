@@ -1,0 +1,203 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the golden vectors captured from the reference
+and vs the C oracle on seeded inputs.  Tolerance (BASELINE.json north_star): 1e-5 relative fp32,
+refined-depth RMSE 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import cspn_monodepth_amd as pkg
+from cspn_monodepth_amd import _lib
+from conftest import golden_names, load_golden, rel_err, rmse
+from oracle import cspn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+RMSE_TOL = 1e-4
+DEV = "cuda:0"
+
+
+def dev(x, dtype=None):
+    if x is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def run3(g, d, s, T, plan=None):
+    m = pkg.CSPN_new.AffinityPropagate(T, 3, plan=plan)
+    with torch.no_grad():
+        out = m(dev(g), dev(d), dev(s))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_native_library_is_loaded():
+    assert _lib.lib().cspn_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libcspn_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", golden_names("g1_") + golden_names("g2_"))
+def test_golden_small_and_degenerate(name):
+    z = load_golden(name)
+    out = run3(z["guidance"], z["blur"], z.get("sparse"), int(z["T"]))
+    assert out.shape == z["out"].shape and out.dtype == np.float32
+    assert rel_err(out, z["out"]) <= REL_TOL, name      # includes identical NaN patterns (1x1, zero gates)
+
+
+@pytest.mark.parametrize("name", golden_names("g3_") + golden_names("g4_"))
+def test_golden_full_frames(name, c_oracle):
+    z = load_golden(name)
+    _, H, W = (int(v) for v in z["shape"])
+    ss = int(z["sparse_samples"])
+    g, d, s = c_oracle.synthetic_inputs(int(z["seed"]), 1, H, W, 8, None if ss < 0 else ss)
+    out = run3(g, d, s, int(z["T"]))
+    sub = int(z["sub"])
+    assert rel_err(out[:, :, ::sub, ::sub], z["out_sub"]) <= REL_TOL
+    assert rmse(out[:, :, ::sub, ::sub], z["out_sub"]) <= RMSE_TOL
+    o64 = out.astype(np.float64)
+    assert np.allclose([o64.sum(), (o64 ** 2).sum()], z["moments"], rtol=1e-6)
+
+
+def test_golden_unet_hook():
+    z = load_golden("g8_unet_hook")
+    g, d, s = (z[k].astype(np.float32) for k in ("guidance_f16", "blur_f16", "sparse_f16"))
+    out = run3(g, d, s, int(z["T"]))
+    assert np.abs(out - z["out"]).max() <= 1e-6 and rmse(out, z["out"]) <= RMSE_TOL
+
+
+PLANS = [
+    None,
+    dict(force_scalar=1),
+    dict(steps_per_launch=1, tile_w=64, tile_h=16, quads_per_thread=1, threads=256),
+    dict(steps_per_launch=1, tile_w=32, tile_h=64, quads_per_thread=2, threads=256),
+    dict(steps_per_launch=2, tile_w=48, tile_h=24, quads_per_thread=2, threads=256),
+    dict(steps_per_launch=3, tile_w=56, tile_h=28, quads_per_thread=2, threads=256),
+    dict(steps_per_launch=4, tile_w=56, tile_h=58, quads_per_thread=4, threads=256),
+    dict(steps_per_launch=5, tile_w=32, tile_h=54, quads_per_thread=4, threads=256),
+    dict(steps_per_launch=6, tile_w=80, tile_h=70, quads_per_thread=4, threads=512),
+    dict(steps_per_launch=8, tile_w=48, tile_h=114, quads_per_thread=8, threads=256),
+    dict(steps_per_launch=12, tile_w=40, tile_h=84, quads_per_thread=8, threads=256),
+    dict(steps_per_launch=24, tile_w=16, tile_h=80, quads_per_thread=8, threads=256),
+]
+
+
+@pytest.mark.parametrize("plan", PLANS, ids=lambda p: "default" if p is None else "-".join(str(v) for v in p.values()))
+@pytest.mark.parametrize("sparse", [False, True])
+def test_plans_vs_oracle(plan, sparse, c_oracle):
+    """Every launch plan (tile shape, quads/thread, fused steps incl. a remainder launch) gives the same answer."""
+    B, H, W, T = 3, 100, 148, 7 if plan and plan.get("steps_per_launch", 1) in (2, 3, 4, 5) else 24
+    g, d, s = c_oracle.synthetic_inputs(11, B, H, W, 12, 300 if sparse else None)
+    want = c_oracle.cspn3_forward(g, d, s, T)
+    out = run3(g, d, s, T, plan)
+    assert rel_err(out, want) <= REL_TOL and rmse(out, want) <= RMSE_TOL
+
+
+def test_nan_spread_matches_reference_under_fusion(c_oracle):
+    """A 0/0 pixel poisons one more ring per step; temporal blocking must reproduce that exactly."""
+    z = load_golden("g2_zero_gates_nan")
+    for plan in (None, dict(steps_per_launch=3, tile_w=8, tile_h=8, quads_per_thread=2, threads=256)):
+        out = run3(z["guidance"], z["blur"], None, int(z["T"]), plan)
+        assert np.array_equal(np.isnan(out), np.isnan(z["out"]))
+        assert rel_err(out, z["out"]) <= REL_TOL
+
+
+def test_full_size_config2_vs_oracle(c_oracle):
+    """BASELINE config 2 (B=24, 228x304, 24 steps, 12-channel guidance as the UNet head emits it)."""
+    g, d, s = c_oracle.synthetic_inputs(1, 24, 228, 304, 12, 500)
+    for sp in (None, s):
+        want = c_oracle.cspn3_forward(g, d, sp, 24)
+        out = run3(g, d, sp, 24)
+        assert rel_err(out, want) <= REL_TOL and rmse(out, want) <= RMSE_TOL
+
+
+def test_size_independent_properties():
+    """At full KITTI size (config 4): constants are fixed points, the map is linear in the depth, and
+    obeys the discrete maximum principle (each step is a convex combination of neighbours)."""
+    torch.manual_seed(0)
+    B, H, W = 2, 352, 1216
+    g = torch.randn(B, 12, H, W, device=DEV)
+    m = pkg.CSPN_new.AffinityPropagate(24, 3)
+    with torch.no_grad():
+        c = m(g, torch.full((B, 1, H, W), 3.25, device=DEV))
+        assert torch.allclose(c, torch.full_like(c, 3.25), rtol=1e-5, atol=0)
+        d1 = torch.rand(B, 1, H, W, device=DEV) * 10
+        d2 = torch.rand(B, 1, H, W, device=DEV) * 10
+        o1, o2, o12 = m(g, d1), m(g, d2), m(g, 0.5 * d1 - 2.0 * d2)
+        assert torch.allclose(o12, 0.5 * o1 - 2.0 * o2, rtol=1e-4, atol=1e-4)
+        assert o1.min() >= d1.min() - 1e-4 and o1.max() <= d1.max() + 1e-4
+        # sparse anchors are restored exactly (CSPN_new.py:90: mask * raw coarse depth)
+        sp = d1 * (torch.rand_like(d1) < 0.01)
+        os_ = m(g, d1, sp)
+        keep = sp > 0
+        assert torch.equal(os_[keep], d1[keep])
+        # only channels 0..7 matter (unet_cspn_nyu.py:332 emits 12)
+        g2 = g.clone()
+        g2[:, 8:] = 123.0
+        assert torch.equal(m(g2, d1), o1)
+
+
+def test_strided_and_noncontiguous_inputs(c_oracle):
+    g, d, s = c_oracle.synthetic_inputs(4, 2, 20, 24, 12, 40)
+    want = c_oracle.cspn3_forward(g, d, s, 5)
+    gt = dev(np.concatenate([g, g], 1))[:, :12]             # non-contiguous batch stride
+    dt = dev(np.concatenate([d, d], 1))[:, :1]
+    with torch.no_grad():
+        out = pkg.CSPN_new.AffinityPropagate(5, 3)(gt, dt, dev(s)).cpu().numpy()
+    assert rel_err(out, want) <= REL_TOL
+
+
+# ------------------------------------------------------------------------------------------------ K x K
+@pytest.mark.parametrize("name", [n for n in golden_names("g6_") if "fp16" not in n])
+def test_pac_golden(name):
+    z = load_golden(name)
+    m = pkg.CSPN_ours.AffinityPropagate(int(z["T"]))
+    with torch.no_grad():
+        out = m(dev(z["x"]), dev(z["guided"]), sparse_depth=dev(z.get("sparse"))).cpu().numpy()
+    assert rel_err(out, z["out"]) <= REL_TOL and rmse(out, z["out"]) <= RMSE_TOL
+
+
+@pytest.mark.parametrize("K,T,plan", [
+    (3, 24, dict(steps_per_launch=4, tile_w=56, tile_h=58, quads_per_thread=4, threads=256)),
+    (5, 12, None),
+    (5, 12, dict(steps_per_launch=2, tile_w=56, tile_h=40, quads_per_thread=3, threads=256)),
+    (5, 12, dict(steps_per_launch=3, tile_w=40, tile_h=36, quads_per_thread=3, threads=256)),
+    (7, 6, None),
+    (7, 6, dict(steps_per_launch=2, tile_w=32, tile_h=18, quads_per_thread=1, threads=256)),
+])
+def test_pac_plans_vs_oracle(K, T, plan, c_oracle):
+    B, H, W = 2, 60, 88
+    gd = c_oracle.hash_normal(K, 1, (B, K * K - 1, H, W))
+    x = c_oracle.hash_uniform(K, 2, (B, 1, H, W), 0.0, 10.0)
+    s = c_oracle.hash_sparse(K, 3, x, 0.05)
+    for sp in (None, s):
+        want = c_oracle.pac_forward(x, gd, sp, T)
+        with torch.no_grad():
+            out = pkg.CSPN_ours.AffinityPropagate(T, plan=plan)(dev(x), dev(gd), sparse_depth=dev(sp)).cpu().numpy()
+        assert rel_err(out, want) <= REL_TOL and rmse(out, want) <= RMSE_TOL
+
+
+def test_pac_fp16_config3():
+    """Config 3 (5x5, 12 steps, fp16): reference semantics = fp16 softmax, fp32 state, fp32 output."""
+    z = load_golden("g6_k5_t12_fp16")
+    x, gd = dev(z["x"]), dev(z["guided"])
+    with torch.no_grad():
+        out = pkg.CSPN_ours.AffinityPropagate(int(z["T"]))(x, gd)
+        out16 = pkg.CSPN_ours.AffinityPropagate(int(z["T"]), state_dtype=None)(x, gd)
+    assert out.dtype == torch.float32 and out16.dtype == torch.float16
+    # fp16 softmax weights carry ~5e-4 relative rounding; the reference rounds them the same way
+    assert rel_err(out.cpu().numpy(), z["out"]) <= 2e-3 and rmse(out.cpu().numpy(), z["out"]) <= 2e-3
+    assert rmse(out16.float().cpu().numpy(), z["out"]) <= 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ metrics
+def test_metrics_kernel_golden():
+    z = load_golden("g7_metrics")
+    ev = pkg.evaluation
+    sums = ev.metric_sums(dev(z["pred"]), dev(z["target"]))
+    want = orc.metric_sums(z["pred"], z["target"])
+    assert np.allclose(sums.cpu().numpy(), want, rtol=1e-5)
+    fin = ev.finalize_metrics(sums.cpu())
+    for k, v in zip(ev.METRIC_NAMES, z["metrics"]):
+        assert np.isclose(fin[k], v, rtol=1e-5), k
+    assert fin["count"] == int((z["target"] > 0).sum())

@@ -1,0 +1,119 @@
+"""CPU tests: the oracle (numpy + C restatements) against the golden vectors captured from the
+imported reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, rel_err, rmse
+from oracle import cspn_oracle as orc
+
+FWD_TOL = 2e-6      # oracle vs reference, fp32 (observed <= 9.6e-7, golden_manifest.json)
+
+
+def _sp(z):
+    return z.get("sparse")
+
+
+@pytest.mark.parametrize("name", golden_names("g1_") + golden_names("g2_"))
+def test_cspn3_forward_small(name, c_oracle):
+    z = load_golden(name)
+    T = int(z["T"])
+    for impl in (orc, c_oracle):
+        out = impl.cspn3_forward(z["guidance"], z["blur"], _sp(z), T)
+        assert out.shape == z["out"].shape
+        assert rel_err(out, z["out"]) <= FWD_TOL, (name, impl.__name__)
+
+
+@pytest.mark.parametrize("name", golden_names("g3_") + golden_names("g4_"))
+def test_cspn3_forward_full_frames(name, c_oracle):
+    """Inputs regenerated from the integer-hash generator; output compared on the stored subsample + moments."""
+    z = load_golden(name)
+    _, H, W = (int(v) for v in z["shape"])
+    ss = int(z["sparse_samples"])
+    g, d, s = c_oracle.synthetic_inputs(int(z["seed"]), 1, H, W, 8, None if ss < 0 else ss)
+    g2, d2, s2 = orc.synthetic_inputs(int(z["seed"]), 1, H, W, 8, None if ss < 0 else ss)
+    assert np.array_equal(g, g2) and np.array_equal(d, d2) and (s is None or np.array_equal(s, s2))
+    out = c_oracle.cspn3_forward(g, d, s, int(z["T"]))
+    sub = int(z["sub"])
+    assert rel_err(out[:, :, ::sub, ::sub], z["out_sub"]) <= FWD_TOL
+    o64 = out.astype(np.float64)
+    mom = np.array([o64.sum(), (o64 ** 2).sum()])
+    assert np.allclose(mom, z["moments"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_names("g5_"))
+def test_cspn3_backward(name, c_oracle):
+    z = load_golden(name)
+    T = int(z["T"])
+    f64 = name.endswith("f64")
+    tol = 1e-10 if f64 else 2e-4
+    for impl in (orc, c_oracle):
+        gg, gd = impl.cspn3_backward(z["guidance"], z["blur"], _sp(z), z["cot"], T, np.float64)
+        scale = max(1.0, float(np.abs(z["grad_guidance"]).max()))
+        assert np.abs(gg - z["grad_guidance"]).max() <= tol * scale, name
+        assert np.abs(gd - z["grad_blur"]).max() <= tol * max(1.0, float(np.abs(z["grad_blur"]).max())), name
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("g6_") if "fp16" not in n])
+def test_pac_forward_backward(name, c_oracle):
+    z = load_golden(name)
+    T = int(z["T"])
+    for impl in (orc, c_oracle):
+        out = impl.pac_forward(z["x"], z["guided"], _sp(z), T)
+        assert rel_err(out, z["out"]) <= FWD_TOL, name
+    gx, gg = orc.pac_backward(z["x"], z["guided"], _sp(z), z["cot"], T, np.float64)
+    assert np.abs(gx - z["grad_x"]).max() <= 1e-10
+    assert np.abs(gg - z["grad_guided"]).max() <= 1e-10
+
+
+def test_pac_fp16_reference_quirk():
+    """The reference promotes everything after the fp16 softmax to fp32 and returns fp32 (CSPN_ours.py:37)."""
+    z = load_golden("g6_k5_t12_fp16")
+    assert z["out"].dtype == np.float32
+    kern16 = orc.pac_kernel(z["guided"].astype(np.float32))[0].astype(np.float16).astype(np.float32)
+    # oracle fed with the fp16-rounded softmax reproduces the reference within fp16 softmax rounding
+    out = orc.pac_forward(z["x"].astype(np.float32), z["guided"].astype(np.float32), None, int(z["T"]))
+    assert rel_err(out, z["out"]) < 2e-3 and rmse(out, z["out"]) < 2e-3
+    assert kern16.shape[1] == 25
+
+
+def test_metrics_golden():
+    z = load_golden("g7_metrics")
+    got, n = orc.evaluate_metrics(z["pred"], z["target"])
+    assert n == int((z["target"] > 0).sum())
+    assert np.allclose(got, z["metrics"], rtol=2e-6)
+    sums = orc.metric_sums(z["pred"], z["target"])
+    assert sums[9] == n
+    assert np.isclose(np.sqrt(sums[2] / n), z["metrics"][3], rtol=2e-6)
+
+
+def test_unet_hook_golden(c_oracle):
+    z = load_golden("g8_unet_hook")
+    g, d, s = (z[k].astype(np.float32) for k in ("guidance_f16", "blur_f16", "sparse_f16"))
+    out = c_oracle.cspn3_forward(g, d, s, int(z["T"]))
+    assert np.abs(out - z["out"]).max() <= 1e-6 and rmse(out, z["out"]) <= 1e-7   # values are O(1e-2)
+
+
+def test_hash_generator_c_equals_numpy(c_oracle):
+    for shape in ((3, 5, 7), (1000,)):
+        assert np.array_equal(orc.hash_uniform(7, 2, shape, -1.0, 3.0), c_oracle.hash_uniform(7, 2, shape, -1.0, 3.0))
+        assert np.array_equal(orc.hash_normal(7, 1, shape), c_oracle.hash_normal(7, 1, shape))
+    n = orc.hash_normal(3, 1, (200000,))
+    assert abs(float(n.mean())) < 0.01 and abs(float(n.std()) - 1.0) < 0.01
+
+
+def test_plumbing_port_matches_oracle():
+    """The cpu_baseline op-mix port (bit-identical to the reference when generated) stays consistent."""
+    import torch
+    from oracle import ref_plumbing_torch as plumb
+    g, d, s = orc.synthetic_inputs(5, 2, 12, 16, 12, 30)
+    with torch.no_grad():
+        out = plumb.cspn3_plumbing(torch.from_numpy(g), torch.from_numpy(d), torch.from_numpy(s), 7).numpy()
+    assert rel_err(out, orc.cspn3_forward(g, d, s, 7)) <= FWD_TOL
+    z = load_golden("g1_c12_t24_sp")
+    with torch.no_grad():
+        out = plumb.cspn3_plumbing(*(torch.from_numpy(z[k]) for k in ("guidance", "blur", "sparse")), 24).numpy()
+    assert rel_err(out, z["out"]) <= FWD_TOL
+    gd = orc.hash_normal(1, 1, (1, 24, 9, 10)); x = orc.hash_uniform(1, 2, (1, 1, 9, 10), 0, 10)
+    with torch.no_grad():
+        out = plumb.pac_plumbing(torch.from_numpy(x), torch.from_numpy(gd), None, 5).numpy()
+    assert rel_err(out, orc.pac_forward(x, gd, None, 5)) <= FWD_TOL
