@@ -501,12 +501,21 @@ __global__ void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __res
         s[8] += ratio < 1.25f * 1.25f * 1.25f ? 1.0 : 0.0;
         s[9] += 1.0;
     }
-    // wave64 shuffle reduction, then one atomic per wave
+    // wave64 shuffle reduction -> LDS -> one atomic per block and quantity (10 per block)
+    __shared__ double part[16][10];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         double v = s[k];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(acc + k, v);
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        double v = 0.0;
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 0; w < nw; ++w) v += part[w][threadIdx.x];
+        if (v != 0.0) atomicAdd(acc + threadIdx.x, v);
     }
 }
 
@@ -554,18 +563,47 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
     return true;
 }
 
-// Built-in plan heuristic (overridable through cspn_plan): see DESIGN.md "plan selection".
+// Built-in plan heuristic (overridable through cspn_plan, or replaced by the host-side autotuner).
+// Rules distilled from plan sweeps on MI355X (profiles/, DESIGN.md "plan selection"):
+//   * temporal blocking pays until the halo re-reads (ratio ~1.6) eat the saved launches: S = 6 / 3 / 2
+//     steps per launch for K = 3 / 5 / 7, balanced over ceil(T/S) launches;
+//   * 512-thread workgroups, 2 (K=3) or 1 quads per thread -> 2 workgroups per CU overlap one tile's
+//     weight stream with the other's LDS steps;
+//   * tile width from {48,64,80,96} with the least padding of W, tile height = the most rows the
+//     workgroup can own, then evened out so the last tile row is not nearly empty.
 void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan* p) {
-    (void)B; (void)H; (void)T; (void)keep_history;
-    p->threads = 256;
+    (void)B; (void)keep_history;
+    const int R = K / 2;
     p->force_scalar = 0;
-    p->steps_per_launch = 1;
-    p->tile_w = W >= 64 ? 64 : round_up4(W);
-    if (K == 3) { p->quads_per_thread = 2; }
-    else if (K == 5) { p->quads_per_thread = 1; }
-    else { p->quads_per_thread = 1; }
-    const int wq = p->tile_w / 4;
-    p->tile_h = (p->threads / wq) * p->quads_per_thread;
+    p->threads = (K == 7) ? 256 : 512;
+    p->quads_per_thread = (K == 3) ? 2 : 1;
+    int S = (K == 3) ? 6 : (K == 5 ? 3 : 2);
+    if (T < 1) T = 1;
+    if (S > T) S = T;
+    S = ceil_div(T, ceil_div(T, S));                 // balance the launches (T=24,S=6 -> 4 x 6)
+    p->steps_per_launch = S;
+    const int hyw = (S - 1) * R, hxw = round_up4(hyw);
+    int best_tw = round_up4(W < 48 ? W : 48), best_waste = 1 << 30;
+    if (W >= 48) {
+        const int cand[4] = {96, 80, 64, 48};
+        for (int i = 0; i < 4; ++i) {
+            const int tw = cand[i];
+            if ((tw + 2 * hxw) / 4 > p->threads / 4) continue;
+            const int waste = ceil_div(W, tw) * tw - W;
+            // prefer less padding; on ties the wider tile (smaller halo ratio)
+            if (waste < best_waste) { best_waste = waste; best_tw = tw; }
+        }
+    }
+    p->tile_w = best_tw;
+    const int wq = (best_tw + 2 * hxw) / 4;
+    int th = p->quads_per_thread * (p->threads / wq) - 2 * hyw;
+    if (th < 4) {                                    // very wide halo for this workgroup: fall back to S = 1
+        p->steps_per_launch = 1;
+        th = p->quads_per_thread * (p->threads / (best_tw / 4));
+    }
+    if (th > H) th = H;
+    th = ceil_div(H, ceil_div(H, th));               // even out the tile rows
+    p->tile_h = th;
 }
 
 void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {
@@ -887,12 +925,12 @@ int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, siz
                             cspn_stream_t stream) {
     if (!pred || !target || !acc10) return fail("cspn_metrics_accumulate: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(n, 256) > 1024 ? 1024 : grid_for(n, 256);
+    const int grid = grid_for(n, 512) > 256 ? 256 : grid_for(n, 512);   // <= one block per CU: 2560 fp64 atomics
     if (dtype == CSPN_F32)
-        hipLaunchKernelGGL((cspn_metrics_kernel<float>), dim3(grid), dim3(256), 0, st,
+        hipLaunchKernelGGL((cspn_metrics_kernel<float>), dim3(grid), dim3(512), 0, st,
                            static_cast<const float*>(pred), static_cast<const float*>(target), n, acc10);
     else if (dtype == CSPN_F16)
-        hipLaunchKernelGGL((cspn_metrics_kernel<__half>), dim3(grid), dim3(256), 0, st,
+        hipLaunchKernelGGL((cspn_metrics_kernel<__half>), dim3(grid), dim3(512), 0, st,
                            static_cast<const __half*>(pred), static_cast<const __half*>(target), n, acc10);
     else
         return fail("cspn_metrics_accumulate: unsupported dtype %d", dtype);

@@ -33,6 +33,68 @@ def resolve_plan(K, B, H, W, T, keep_history=False, plan=None):
     return {name: int(getattr(out, name)) for name, _ in cspn_plan._fields_}
 
 
+_TUNED = {}          # autotune cache: problem key -> plan dict
+_NQ_THREADS = {3: ((1, 256), (2, 256), (4, 256), (2, 512), (4, 512)),
+               5: ((1, 256), (2, 256), (3, 256), (1, 512)),
+               7: ((1, 256),)}
+_S_LIST = {3: (1, 3, 4, 5, 6, 8), 5: (1, 2, 3, 4), 7: (1, 2)}
+
+
+def candidate_plans(K, H, W, T):
+    """Launch plans worth timing for a problem (the sweep space of tools/tune.py, pruned)."""
+    R = K // 2
+    widths = sorted({w for w in (32, 48, 64, 80, 96, 128) if w <= W + 3} |
+                    {-(-(-(-W // n)) // 4) * 4 for n in (1, 2, 3, 4, 5, 6, 8) if -(-W // n) >= 16} or {-(-W // 4) * 4})
+    plans = []
+    for S in _S_LIST[K]:
+        if S > max(T, 1):
+            continue
+        hyw = (S - 1) * R
+        hxw = -(-hyw // 4) * 4
+        for nq, threads in _NQ_THREADS[K]:
+            for tw in widths:
+                wq = (tw + 2 * hxw) // 4
+                if wq > threads:
+                    continue
+                th_max = min(nq * (threads // wq) - 2 * hyw, H)
+                if th_max < min(4, H):
+                    continue
+                for th in {th_max, -(-H // -(-H // th_max))}:
+                    plans.append(dict(steps_per_launch=S, tile_w=tw, tile_h=th, quads_per_thread=nq, threads=threads))
+    return plans
+
+
+def autotune_plan(w, d0, sparse, K, T, blend, keep_history=False, reps=3, verbose=False):
+    """Time candidate_plans() on the actual tensors (HIP events on the current stream) and cache the fastest.
+
+    Opt-in (`plan="auto"`): costs a few tens of ms once per (shape, dtype, blend) key."""
+    B, NT, H, W = w.shape
+    key = (int(K), B, H, W, int(T), w.dtype, d0.dtype, int(blend), bool(keep_history), w.device.index)
+    if key in _TUNED:
+        return _TUNED[key]
+    best, best_us = None, float("inf")
+    if W % 4 == 0 and T > 0:
+        for plan in candidate_plans(K, H, W, T):
+            try:
+                resolve_plan(K, B, H, W, T, keep_history, plan)
+                propagate(w, d0, sparse, K, T, blend, keep_history, plan)        # warm-up / validates the launch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    propagate(w, d0, sparse, K, T, blend, keep_history, plan)
+                e1.record()
+                e1.synchronize()
+            except RuntimeError:
+                continue
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            if us < best_us:
+                best, best_us = plan, us
+    if verbose:
+        print("autotune K=%d B=%d %dx%d T=%d -> %s (%.1f us)" % (K, B, H, W, T, best, best_us))
+    _TUNED[key] = best        # None = keep the built-in heuristic
+    return best
+
+
 def set_default_plan(K, plan):
     """plan: None or dict(steps_per_launch=, tile_w=, tile_h=, quads_per_thread=, threads=, force_scalar=)."""
     if plan is None:
@@ -43,7 +105,7 @@ def set_default_plan(K, plan):
 
 def _plan_ptr(K, plan):
     plan = _DEFAULT_PLANS.get(int(K)) if plan is None else plan
-    if plan is None:
+    if plan is None or isinstance(plan, str):
         return None
     if isinstance(plan, cspn_plan):
         return ctypes.pointer(plan)
@@ -156,6 +218,10 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
     L = _lib.lib()
     hist = out = work = None
     T = int(T)
+    if isinstance(plan, str):
+        if plan != "auto":
+            raise ValueError("plan must be None, a dict, a cspn_plan or 'auto'")
+        plan = autotune_plan(w, d0, sparse, K, T, blend, keep_history)
     if keep_history and T > 0:
         hist = torch.empty((T, B, H, W), dtype=d0.dtype, device=dev)
     else:
