@@ -70,7 +70,8 @@ def make_inputs(wl, B, device, seed, sparse):
 def cpu_baseline(wl, budget_s=16.0):
     """The reference's CPU op mix (oracle/ref_plumbing_torch.py, a port validated bit-identical to the imported
     reference) on this box's host cores, on a bounded sample of the same workload: single frames and a
-    4-frame batch of the workload's shape, at two thread counts (oneDNN's 5-D conv path scales badly with both
+    4-frame batch of the workload's shape, at up to three thread counts (8/16/32, capped by the core count;
+    256 threads take >60 s per frame) (oneDNN's 5-D conv path scales badly with both
     batch and threads); the best rate is reported."""
     from oracle import ref_plumbing_torch as plumb
     from oracle import c_oracle
@@ -89,7 +90,7 @@ def cpu_baseline(wl, budget_s=16.0):
     tried = []
     t_begin = time.perf_counter()
     with torch.no_grad():
-        for threads in sorted({min(cores, 16), cores}):
+        for threads in sorted({min(cores, 8), min(cores, 16), min(cores, 32)}):
             torch.set_num_threads(threads)
             for b in (1, 4):
                 if time.perf_counter() - t_begin > budget_s:

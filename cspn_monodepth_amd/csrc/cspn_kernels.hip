@@ -91,8 +91,12 @@ struct PropArgs {
     int dr, ls;          // depth region rows, LDS row stride (floats)
 };
 
+// Minimum waves per SIMD requested from the register allocator: the one-quad 3x3 instance is held to
+// 64 VGPRs (8 waves/SIMD, i.e. 8/4/2 workgroups of 256/512/1024 threads per CU); the others take what they need.
+template <int K, int NQ> struct MinWaves { static constexpr int value = (K == 3 && NQ == 1) ? 8 : 1; };
+
 template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND>
-__global__ __launch_bounds__(NTHREADS) void cspn_prop_fused(const PropArgs a) {
+__global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_fused(const PropArgs a) {
     constexpr int R = K / 2;
     constexpr int NT = K * K - 1;
     constexpr int WIN = 4 + 2 * R;
@@ -478,15 +482,13 @@ __global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const flo
 // evaluation metrics: masked sums (libs/metrics.py:49-83)
 // ------------------------------------------------------------------------------------------------
 template <typename DT>
-__global__ void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __restrict__ target, size_t n,
-                                    double* __restrict__ acc) {
+__global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __restrict__ target,
+                                                            size_t n, int vec_ok, double* __restrict__ acc) {
     double s[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) s[k] = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float t = ld1(target + i);
-        if (!(t > 0.f)) continue;
-        const float o = ld1(pred + i);
+    auto one = [&](float o, float t) {
+        if (!(t > 0.f)) return;
         const float ad = fabsf(o - t);
         const float inv = fabsf(1.f / o - 1.f / t);
         const float ratio = fmaxf(o / t, t / o);
@@ -500,7 +502,15 @@ __global__ void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __res
         s[7] += ratio < 1.25f * 1.25f ? 1.0 : 0.0;
         s[8] += ratio < 1.25f * 1.25f * 1.25f ? 1.0 : 0.0;
         s[9] += 1.0;
+    };
+    const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * blockDim.x;
+    const size_t nq = vec_ok ? n / 4 : 0;
+    for (size_t q = gtid; q < nq; q += gsz) {
+        const float4 o = ld4(pred + 4 * q), t = ld4(target + 4 * q);
+        one(o.x, t.x); one(o.y, t.y); one(o.z, t.z); one(o.w, t.w);
     }
+    for (size_t i = 4 * nq + gtid; i < n; i += gsz) one(ld1(pred + i), ld1(target + i));
     // wave64 shuffle reduction -> LDS -> one atomic per block and quantity (10 per block)
     __shared__ double part[16][10];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -522,6 +532,7 @@ __global__ void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __res
 // ------------------------------------------------------------------------------------------------
 // host side: plan selection and launches
 // ------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up4(int a) { return (a + 3) & ~3; }
 inline size_t esize(int dt) { return dt == CSPN_F16 ? 2 : 4; }
@@ -652,7 +663,7 @@ int launch_fused(const Launch& L, int blend, hipStream_t st) {
     if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT>(L, blend, st)
     if constexpr (K == 3) {
         CSPN_CASE(1, 256); CSPN_CASE(2, 256); CSPN_CASE(4, 256); CSPN_CASE(8, 256);
-        CSPN_CASE(2, 512); CSPN_CASE(4, 512);
+        CSPN_CASE(1, 512); CSPN_CASE(2, 512); CSPN_CASE(4, 512); CSPN_CASE(1, 1024); CSPN_CASE(2, 1024);
     } else if constexpr (K == 5) {
         CSPN_CASE(1, 256); CSPN_CASE(2, 256); CSPN_CASE(3, 256); CSPN_CASE(1, 512);
     } else {
@@ -681,8 +692,6 @@ int launch_scalar(const void* w, const void* din, void* dout, const void* sp, co
     HIP_OK(hipGetLastError());
     return 1;
 }
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int K, typename WT, typename DT>
 int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
@@ -925,13 +934,14 @@ int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, siz
                             cspn_stream_t stream) {
     if (!pred || !target || !acc10) return fail("cspn_metrics_accumulate: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(n, 512) > 256 ? 256 : grid_for(n, 512);   // <= one block per CU: 2560 fp64 atomics
+    const int grid = grid_for(n / 4 + 1, 1024) > 256 ? 256 : grid_for(n / 4 + 1, 1024);   // <= one block per CU
+    const int vec_ok = aligned16(pred) && aligned16(target);
     if (dtype == CSPN_F32)
-        hipLaunchKernelGGL((cspn_metrics_kernel<float>), dim3(grid), dim3(512), 0, st,
-                           static_cast<const float*>(pred), static_cast<const float*>(target), n, acc10);
+        hipLaunchKernelGGL((cspn_metrics_kernel<float>), dim3(grid), dim3(1024), 0, st,
+                           static_cast<const float*>(pred), static_cast<const float*>(target), n, vec_ok, acc10);
     else if (dtype == CSPN_F16)
-        hipLaunchKernelGGL((cspn_metrics_kernel<__half>), dim3(grid), dim3(512), 0, st,
-                           static_cast<const __half*>(pred), static_cast<const __half*>(target), n, acc10);
+        hipLaunchKernelGGL((cspn_metrics_kernel<__half>), dim3(grid), dim3(1024), 0, st,
+                           static_cast<const __half*>(pred), static_cast<const __half*>(target), n, vec_ok, acc10);
     else
         return fail("cspn_metrics_accumulate: unsupported dtype %d", dtype);
     HIP_OK(hipGetLastError());

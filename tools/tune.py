@@ -75,7 +75,7 @@ def main():
                 continue
             hyw = (S - 1) * R
             hxw = (hyw + 3) // 4 * 4
-            for threads in (256, 512):
+            for threads in (256, 512, 1024):
                 for nq in nqs:
                     for tw in (16, 24, 32, 40, 48, 56, 64, 76, 80, 96, 104, 112, 128, 152, 160, 192, 256, 304):
                         if tw > W + 3:
