@@ -13,7 +13,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SO_PATH = os.path.join(_PKG, "libcspn_hip.so")
+SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 SRC = os.path.join(_PKG, "csrc", "cspn_kernels.hip")
 INCLUDE = os.path.join(_ROOT, "include")
 
@@ -40,7 +40,10 @@ def build(force=False, verbose=False):
         return SO_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-fast-math", "-I", INCLUDE, "-o", SO_PATH + ".tmp", SRC]
+           # -fno-slp-vectorize: the SLP pass pairs the stencil FMAs into v_pk_fma_f32 and pays for it with
+           # ~50 v_mov per step to build operand pairs; scalar v_fma_f32 measured 4 % faster (profiles/).
+           "-fno-fast-math", "-fno-slp-vectorize"] + os.environ.get("CSPN_HIPCC_FLAGS", "").split() + [
+           "-I", INCLUDE, "-o", SO_PATH + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -66,6 +66,18 @@ __device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 __device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) v4f* lds_cv4f_ptr;   // LDS (addrspace 3) volatile b128
+
+// Wavefront-level halo exchange: value held by lane-1 / lane+1 (DPP wave shift, VALU only).  Lanes without
+// a source (0 / 63) or with an exec-masked source get 0 and are patched from LDS by the caller.
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_next_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // blockIdx -> logical tile id such that XCD x (= blockIdx % 8, observed dispatch order; speed only,
 // never correctness) processes one contiguous range of tiles.
 __device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
@@ -190,24 +202,49 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     // ---- 3. S propagation steps in LDS ------------------------------------------------------------
     const bool active = (r0 < wr);
     const int cb = 4 + 4 * sx;
+    const int lane = tid & 63;
+    const bool fix_left = (sx == 0) || (lane == 0);          // left neighbour quad is not lane-1's
+    const bool fix_right = (sx == wq - 1) || (lane == 63);   // right neighbour quad is not lane+1's
     DT* __restrict__ dout = a.d_out ? static_cast<DT*>(a.d_out) + (size_t)b * HW : nullptr;
     DT* __restrict__ hist = a.hist ? static_cast<DT*>(a.hist) + (size_t)b * HW : nullptr;
 
     for (int s = 1; s <= a.S; ++s) {
         const bool last = (s == a.S);
         if (active) {
+            // Window fetch.  One aligned ds_read_b128 per row gives the thread's own 4 pixels; the R pixels
+            // to the left / right are the neighbouring lanes' quads, taken with DPP wave shifts (no LDS
+            // traffic, no bank conflicts).  Only the lanes at the ends of a strip row (and wave lanes 0 / 63)
+            // fetch their halo from LDS, in two exec-masked blocks.
             float win[NQ + 2 * R][WIN];
+            const float* rowp[NQ + 2 * R];
 #pragma unroll
             for (int rr = 0; rr < NQ + 2 * R; ++rr) {
                 int drow = r0 + rr;
                 drow = drow < dr ? drow : dr - 1;
-                const float* rowp = cur + drow * ls + cb;
-                const float4 mid = *reinterpret_cast<const float4*>(rowp);
+                rowp[rr] = cur + drow * ls + cb;
+                // volatile: keep this ONE ds_read_b128.  Left alone, the optimiser re-loads overlapping
+                // dword pairs from LDS (bank-conflicted ds_read2_b32) to feed v_pk_fma_f32 operand pairs.
+                const v4f mid = *(lds_cv4f_ptr)(rowp[rr]);
+                const float m4[4] = {mid.x, mid.y, mid.z, mid.w};
 #pragma unroll
-                for (int c = 0; c < R; ++c) win[rr][c] = rowp[c - R];
-                win[rr][R + 0] = mid.x; win[rr][R + 1] = mid.y; win[rr][R + 2] = mid.z; win[rr][R + 3] = mid.w;
+                for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
 #pragma unroll
-                for (int c = 0; c < R; ++c) win[rr][R + 4 + c] = rowp[4 + c];
+                for (int c = 0; c < R; ++c) {
+                    win[rr][c] = dpp_from_prev_lane(m4[4 - R + c]);
+                    win[rr][R + 4 + c] = dpp_from_next_lane(m4[c]);
+                }
+            }
+            if (fix_left) {
+#pragma unroll
+                for (int rr = 0; rr < NQ + 2 * R; ++rr)
+#pragma unroll
+                    for (int c = 0; c < R; ++c) win[rr][c] = rowp[rr][c - R];
+            }
+            if (fix_right) {
+#pragma unroll
+                for (int rr = 0; rr < NQ + 2 * R; ++rr)
+#pragma unroll
+                    for (int c = 0; c < R; ++c) win[rr][R + 4 + c] = rowp[rr][4 + c];
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -484,24 +521,29 @@ __global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const flo
 template <typename DT>
 __global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __restrict__ target,
                                                             size_t n, int vec_ok, double* __restrict__ acc) {
-    double s[10];
+    // Per-thread partial sums stay in fp32 (a thread sees ~a dozen pixels); fp64 starts at the wave reduction.
+    // Algebraically equal forms that avoid cancellation and redundant divisions:
+    //   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)|,
+    //   max(o/t, t/o) < c  <=>  o < c t  and  (o > 0 ? t < c o : o < 0)      (t > 0; NaN -> false as torch.max)
+    float f[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) s[k] = 0.0;
+    for (int k = 0; k < 10; ++k) f[k] = 0.f;
     auto one = [&](float o, float t) {
         if (!(t > 0.f)) return;
         const float ad = fabsf(o - t);
-        const float inv = fabsf(1.f / o - 1.f / t);
-        const float ratio = fmaxf(o / t, t / o);
-        s[0] += (double)inv * inv;
-        s[1] += inv;
-        s[2] += (double)ad * ad;
-        s[3] += ad;
-        s[4] += ad / t;
-        s[5] += fabsf(log10f(o) - log10f(t));
-        s[6] += ratio < 1.25f ? 1.0 : 0.0;
-        s[7] += ratio < 1.25f * 1.25f ? 1.0 : 0.0;
-        s[8] += ratio < 1.25f * 1.25f * 1.25f ? 1.0 : 0.0;
-        s[9] += 1.0;
+        const float inv = ad / fabsf(o * t);
+        f[0] = fmaf(inv, inv, f[0]);
+        f[1] += inv;
+        f[2] = fmaf(ad, ad, f[2]);
+        f[3] += ad;
+        f[4] += ad / t;
+        f[5] += fabsf(log10f(o / t));
+        const float c1 = 1.25f, c2 = 1.25f * 1.25f, c3 = 1.25f * 1.25f * 1.25f;
+        const bool pos = o > 0.f, neg = o < 0.f;
+        f[6] += (o < c1 * t && (pos ? t < c1 * o : neg)) ? 1.f : 0.f;
+        f[7] += (o < c2 * t && (pos ? t < c2 * o : neg)) ? 1.f : 0.f;
+        f[8] += (o < c3 * t && (pos ? t < c3 * o : neg)) ? 1.f : 0.f;
+        f[9] += 1.f;
     };
     const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * blockDim.x;
@@ -511,6 +553,9 @@ __global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict
         one(o.x, t.x); one(o.y, t.y); one(o.z, t.z); one(o.w, t.w);
     }
     for (size_t i = 4 * nq + gtid; i < n; i += gsz) one(ld1(pred + i), ld1(target + i));
+    double s[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = (double)f[k];
     // wave64 shuffle reduction -> LDS -> one atomic per block and quantity (10 per block)
     __shared__ double part[16][10];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -575,46 +620,43 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
 }
 
 // Built-in plan heuristic (overridable through cspn_plan, or replaced by the host-side autotuner).
-// Rules distilled from plan sweeps on MI355X (profiles/, DESIGN.md "plan selection"):
-//   * temporal blocking pays until the halo re-reads (ratio ~1.6) eat the saved launches: S = 6 / 3 / 2
-//     steps per launch for K = 3 / 5 / 7, balanced over ceil(T/S) launches;
-//   * 512-thread workgroups, 2 (K=3) or 1 quads per thread -> 2 workgroups per CU overlap one tile's
-//     weight stream with the other's LDS steps;
-//   * tile width from {48,64,80,96} with the least padding of W, tile height = the most rows the
-//     workgroup can own, then evened out so the last tile row is not nearly empty.
+// Rules distilled from plan sweeps on MI355X (profiles/r01_plan_sweep_*.txt, DESIGN.md "plan selection"):
+//   * temporal blocking pays until the halo work (ratio ~1.8) eats the saved launches: S0 = 8 / 3 / 2 steps
+//     per launch for K = 3 / 5 / 7, balanced over ceil(T/S0) launches;
+//   * one quad per thread (<= 64 VGPRs at K=3 -> 8 waves/SIMD) and the largest workgroup: two 1024-thread
+//     workgroups per CU overlap one tile's weight stream with the other's LDS steps;
+//   * tile width = W split into n equal parts (rounded up to whole quads), tile height = every row the
+//     workgroup can own, evened out over the image; the (n, height) pair with the fewest total
+//     weight-region pixels (tiles x (tile + halo)) wins, wider tile on ties.
 void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan* p) {
     (void)B; (void)keep_history;
     const int R = K / 2;
     p->force_scalar = 0;
-    p->threads = (K == 7) ? 256 : 512;
-    p->quads_per_thread = (K == 3) ? 2 : 1;
-    int S = (K == 3) ? 6 : (K == 5 ? 3 : 2);
+    p->threads = (K == 3) ? 1024 : (K == 5 ? 512 : 256);
+    p->quads_per_thread = 1;
+    int S = (K == 3) ? 8 : (K == 5 ? 3 : 2);
     if (T < 1) T = 1;
     if (S > T) S = T;
-    S = ceil_div(T, ceil_div(T, S));                 // balance the launches (T=24,S=6 -> 4 x 6)
-    p->steps_per_launch = S;
-    const int hyw = (S - 1) * R, hxw = round_up4(hyw);
-    int best_tw = round_up4(W < 48 ? W : 48), best_waste = 1 << 30;
-    if (W >= 48) {
-        const int cand[4] = {96, 80, 64, 48};
-        for (int i = 0; i < 4; ++i) {
-            const int tw = cand[i];
-            if ((tw + 2 * hxw) / 4 > p->threads / 4) continue;
-            const int waste = ceil_div(W, tw) * tw - W;
-            // prefer less padding; on ties the wider tile (smaller halo ratio)
-            if (waste < best_waste) { best_waste = waste; best_tw = tw; }
+    S = ceil_div(T, ceil_div(T, S));                 // balance the launches (T=24, S0=8 -> 3 x 8)
+    for (;; --S) {                                   // shrink S until some tiling fits the workgroup
+        const int hyw = (S - 1) * R, hxw = round_up4(hyw);
+        long best_cost = -1;
+        for (int n = 1; n <= 64; ++n) {
+            const int tw = round_up4(ceil_div(W, n));
+            if (n > 1 && tw < 16) break;
+            const int wq = (tw + 2 * hxw) / 4;
+            if (wq > p->threads) continue;
+            int th = p->quads_per_thread * (p->threads / wq) - 2 * hyw;
+            if (th > H) th = H;
+            if (th < 1 || (th < 8 && th < H)) continue;
+            th = ceil_div(H, ceil_div(H, th));       // even out the tile rows
+            const long cost = (long)ceil_div(W, tw) * ceil_div(H, th) * (4L * wq) * (th + 2 * hyw);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; p->tile_w = tw; p->tile_h = th; }
         }
+        if (best_cost >= 0 || S == 1) break;
     }
-    p->tile_w = best_tw;
-    const int wq = (best_tw + 2 * hxw) / 4;
-    int th = p->quads_per_thread * (p->threads / wq) - 2 * hyw;
-    if (th < 4) {                                    // very wide halo for this workgroup: fall back to S = 1
-        p->steps_per_launch = 1;
-        th = p->quads_per_thread * (p->threads / (best_tw / 4));
-    }
-    if (th > H) th = H;
-    th = ceil_div(H, ceil_div(H, th));               // even out the tile rows
-    p->tile_h = th;
+    p->steps_per_launch = S;
+    if (p->tile_w <= 0) { p->tile_w = round_up4(W < 64 ? W : 64); p->tile_h = p->threads / (p->tile_w / 4); }
 }
 
 void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {

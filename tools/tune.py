@@ -77,7 +77,7 @@ def main():
             hxw = (hyw + 3) // 4 * 4
             for threads in (256, 512, 1024):
                 for nq in nqs:
-                    for tw in (16, 24, 32, 40, 48, 56, 64, 76, 80, 96, 104, 112, 128, 152, 160, 192, 256, 304):
+                    for tw in sorted(set(range(16, 161, 8)) | {(-(-W // n) + 3) // 4 * 4 for n in range(1, 17)}):
                         if tw > W + 3:
                             continue
                         wq = (tw + 2 * hxw) // 4
