@@ -176,7 +176,7 @@ def main():
             del w_
         module.plan = plan
     eff_plan = F.resolve_plan(K, B_local, wl["H"], wl["W"], T, False, plan)
-    sums = torch.zeros(pkg.evaluation.N_SUMS, dtype=torch.float64, device=device)
+    sums = pkg.evaluation.new_accumulator(device)
 
     def step():
         out = run()

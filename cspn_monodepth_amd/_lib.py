@@ -70,7 +70,7 @@ def _declare(lib):
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
     lib.cspn_pac_grad_guided.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, vp]
+    lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, ci, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes"):

@@ -520,7 +520,8 @@ __global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const flo
 // ------------------------------------------------------------------------------------------------
 template <typename DT>
 __global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict__ pred, const DT* __restrict__ target,
-                                                            size_t n, int vec_ok, double* __restrict__ acc) {
+                                                            size_t n, int vec_ok, double* __restrict__ acc,
+                                                            int nslots) {
     // Per-thread partial sums stay in fp32 (a thread sees ~a dozen pixels); fp64 starts at the wave reduction.
     // Algebraically equal forms that avoid cancellation and redundant divisions:
     //   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)|,
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict
         double v = 0.0;
         const int nw = (blockDim.x + 63) >> 6;
         for (int w = 0; w < nw; ++w) v += part[w][threadIdx.x];
-        if (v != 0.0) atomicAdd(acc + threadIdx.x, v);
+        // contention on one address costs ~45 ns per atomic: spread the blocks over `nslots` accumulator rows
+        if (v != 0.0) atomicAdd(acc + (size_t)(blockIdx.x % nslots) * 10 + threadIdx.x, v);
     }
 }
 
@@ -972,18 +974,18 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
     return fail("cspn_pac_grad_guided: unsupported K=%d", K);
 }
 
-int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, size_t n, double* acc10,
+int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, size_t n, double* acc, int nslots,
                             cspn_stream_t stream) {
-    if (!pred || !target || !acc10) return fail("cspn_metrics_accumulate: NULL pointer");
+    if (!pred || !target || !acc || nslots < 1) return fail("cspn_metrics_accumulate: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n / 4 + 1, 1024) > 256 ? 256 : grid_for(n / 4 + 1, 1024);   // <= one block per CU
     const int vec_ok = aligned16(pred) && aligned16(target);
     if (dtype == CSPN_F32)
         hipLaunchKernelGGL((cspn_metrics_kernel<float>), dim3(grid), dim3(1024), 0, st,
-                           static_cast<const float*>(pred), static_cast<const float*>(target), n, vec_ok, acc10);
+                           static_cast<const float*>(pred), static_cast<const float*>(target), n, vec_ok, acc, nslots);
     else if (dtype == CSPN_F16)
         hipLaunchKernelGGL((cspn_metrics_kernel<__half>), dim3(grid), dim3(1024), 0, st,
-                           static_cast<const __half*>(pred), static_cast<const __half*>(target), n, vec_ok, acc10);
+                           static_cast<const __half*>(pred), static_cast<const __half*>(target), n, vec_ok, acc, nslots);
     else
         return fail("cspn_metrics_accumulate: unsupported dtype %d", dtype);
     HIP_OK(hipGetLastError());

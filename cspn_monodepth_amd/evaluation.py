@@ -17,6 +17,12 @@ from . import _lib
 
 METRIC_NAMES = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
 N_SUMS = 10   # {inv^2, inv, diff^2, diff, diff/t, |dlog10|, #<1.25, #<1.25^2, #<1.25^3, n}
+N_SLOTS = 32  # accumulator rows the kernel spreads its fp64 atomics over (added up by finalize / all-gather)
+
+
+def new_accumulator(device):
+    """Zeroed [N_SLOTS, 10] float64 accumulator for metric_sums(..., out=acc) in a loop over batches."""
+    return torch.zeros((N_SLOTS, N_SUMS), dtype=torch.float64, device=device)
 
 
 def shard_bounds(n_items, rank, world_size):
@@ -27,28 +33,34 @@ def shard_bounds(n_items, rank, world_size):
 
 
 def metric_sums(pred, target, out=None):
-    """Masked sums over target > 0 as a float64[10] device tensor (one fused HIP reduction kernel).
+    """Masked sums over target > 0 (one fused HIP reduction kernel).
 
-    `out` (float64[10]) is accumulated into when given, so a loop over batches needs no host sync."""
+    Without `out`: returns the float64[10] sums.  With `out` (from new_accumulator): accumulates into its
+    rows and returns it, so a loop over batches needs neither a host sync nor an extra reduction launch."""
     if not (pred.is_cuda and target.is_cuda):
         raise RuntimeError("metric_sums: tensors must live on a ROCm device (no CPU implementation here)")
     if pred.shape != target.shape or pred.dtype != target.dtype:
         raise ValueError("pred / target must have the same shape and dtype")
     p, t = pred.contiguous(), target.contiguous()
-    acc = torch.zeros(N_SUMS, dtype=torch.float64, device=p.device) if out is None else out
+    acc = new_accumulator(p.device) if out is None else out
+    if acc.dtype != torch.float64 or acc.dim() != 2 or acc.shape[1] != N_SUMS or not acc.is_contiguous():
+        raise ValueError("out must be a contiguous float64 [nslots, 10] tensor (evaluation.new_accumulator)")
     dt = _lib.CSPN_F32 if p.dtype == torch.float32 else _lib.CSPN_F16 if p.dtype == torch.float16 else None
     if dt is None:
         raise TypeError("metric_sums supports float32 / float16")
     with torch.cuda.device(p.device):
         ok = _lib.lib().cspn_metrics_accumulate(
             ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(t.data_ptr()), dt, p.numel(),
-            ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+            ctypes.c_void_p(acc.data_ptr()), int(acc.shape[0]),
+            ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
     _lib.check(ok, "cspn_metrics_accumulate")
-    return acc
+    return acc.sum(0) if out is None else acc
 
 
 def finalize_metrics(sums):
     """float64[10] sums -> dict of the reference's 10 metrics + 'count'."""
+    if hasattr(sums, "dim") and sums.dim() == 2:
+        sums = sums.sum(0)
     s = [float(v) for v in sums]
     n = s[9]
     if n <= 0:
@@ -61,6 +73,8 @@ def finalize_metrics(sums):
 
 def all_gather_metric_sums(sums, group=None):
     """All-gather the per-rank sums (world x 10 float64) and add them.  Works with gloo (CPU) and nccl/RCCL."""
+    if sums.dim() == 2:
+        sums = sums.sum(0)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return sums.clone(), sums.unsqueeze(0).clone()
     world = dist.get_world_size(group)

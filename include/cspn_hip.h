@@ -123,11 +123,12 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
 
 /* ---- evaluation (libs/metrics.py:49-83, base_model.py:28-73) ------------ */
 
-/* acc[0..9] (f64, zero-initialised by the caller) += masked sums over target>0 of
+/* acc[nslots][10] (f64, zero-initialised by the caller): row (block % nslots) += masked sums over target>0 of
  * {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), n};
- * the host turns them into irmse, imae, mse, rmse, mae, absrel, lg10, delta1..3 (+ the count n). */
+ * the host adds the rows and turns them into irmse, imae, mse, rmse, mae, absrel, lg10, delta1..3 (+ n).
+ * Several rows only spread the fp64 atomics (one address serialises at ~45 ns each); nslots = 1 is valid. */
 int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, size_t n,
-                            double* acc10, cspn_stream_t stream);
+                            double* acc, int nslots, cspn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -201,3 +201,16 @@ def test_metrics_kernel_golden():
     for k, v in zip(ev.METRIC_NAMES, z["metrics"]):
         assert np.isclose(fin[k], v, rtol=1e-5), k
     assert fin["count"] == int((z["target"] > 0).sum())
+    # accumulating form: two batches into one [nslots, 10] accumulator, no host sync in between
+    acc = ev.new_accumulator(DEV)
+    ev.metric_sums(dev(z["pred"]), dev(z["target"]), out=acc)
+    ev.metric_sums(dev(z["pred"]), dev(z["target"]), out=acc)
+    assert np.allclose(acc.sum(0).cpu().numpy(), 2 * want, rtol=1e-5)
+    assert ev.finalize_metrics(acc.cpu())["count"] == 2 * fin["count"]
+    # a full-size batch (odd length -> scalar tail) against the numpy oracle
+    rng = np.random.default_rng(0)
+    t = rng.uniform(0.5, 10, 24 * 228 * 304 + 3).astype(np.float32)
+    t[rng.random(t.size) < 0.05] = 0
+    p = np.abs(t + rng.normal(0, 0.1, t.size).astype(np.float32)) + 0.01
+    got = ev.metric_sums(dev(p.astype(np.float32)), dev(t)).cpu().numpy()
+    assert np.allclose(got, orc.metric_sums(p.astype(np.float32), t), rtol=2e-5)

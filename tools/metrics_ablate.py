@@ -6,6 +6,6 @@ import cspn_monodepth_amd as pkg
 from tools.tune import timed
 d = torch.rand(24, 1, 228, 304, device="cuda") * 10 + 0.1
 t = d + 0.1
-acc = torch.zeros(10, dtype=torch.float64, device="cuda")
+acc = pkg.evaluation.new_accumulator("cuda")
 print("metric_sums: %.1f us" % timed(lambda: pkg.evaluation.metric_sums(d, t, out=acc), 50))
 print("torch sum  : %.1f us" % timed(lambda: (d - t).abs().sum(), 50))

@@ -63,7 +63,9 @@ def main():
         ref, _ = F.propagate(w, d0, sp, K, T, blend, plan=dict(steps_per_launch=1, tile_w=64, tile_h=16,
                                                                quads_per_thread=1, threads=256))
         out = torch.empty_like(ref)
-        t_met = timed(lambda: pkg.evaluation.metric_sums(ref, target[:, 0].contiguous()), 20)
+        acc = pkg.evaluation.new_accumulator(dev)
+        tgt = target[:, 0].contiguous()
+        t_met = timed(lambda: pkg.evaluation.metric_sums(ref, tgt, out=acc), 20)
         print("prepare %.1f us   metrics %.1f us" % (t_prep, t_met), flush=True)
         esz = 2 if wl["dtype"] == "f16" else 4
         alg = (K * K + 1 + (2 if sp is not None else 0)) * esz * B * H * W * T
