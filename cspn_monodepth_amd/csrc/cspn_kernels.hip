@@ -141,8 +141,12 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
 
     // ---- 1. issue the weight stream first (independent of LDS): NQ x NT 16-byte loads -----------
     float wreg[NQ][NT][4];
-    float mreg[NQ][4], d0reg[NQ][4];
     unsigned in_img = 0, interior = 0;
+    // Blend operands of the owned quads, om = 1 - m and md0 = m * d0 (m = sign(sparse); both products are exact),
+    // are parked in two private LDS planes instead of 8 VGPRs per quad: each thread only ever touches its
+    // own slots, so no barrier is involved, and the one-quad instances stay within 64 VGPRs.
+    float* const om_lds = lds + (size_t)2 * a.dr * a.ls;
+    float* const md_lds = om_lds + (size_t)a.wr * 4 * a.wq;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int r = r0 + i, y = yq0 + i;
@@ -156,13 +160,14 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
             const float4 v = ok ? ld4(wg + (size_t)j * HW + off) : z4;
             wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
         }
-        if (BLEND) {
-            const float4 v = ok ? sgn4(ld4(spg + off)) : z4;
-            mreg[i][0] = v.x; mreg[i][1] = v.y; mreg[i][2] = v.z; mreg[i][3] = v.w;
-        }
-        if (BLEND == CSPN_BLEND_SPARSE) {
-            const float4 v = ok ? ld4(static_cast<const DT*>(a.d0) + (size_t)b * HW + off) : z4;
-            d0reg[i][0] = v.x; d0reg[i][1] = v.y; d0reg[i][2] = v.z; d0reg[i][3] = v.w;
+        if (BLEND && r < wr) {
+            const float4 m = ok ? sgn4(ld4(spg + off)) : z4;
+            const int qoff = (r * wq + sx) * 4;
+            *reinterpret_cast<float4*>(om_lds + qoff) = make_float4(1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w);
+            if (BLEND == CSPN_BLEND_SPARSE) {
+                const float4 v = ok ? ld4(static_cast<const DT*>(a.d0) + (size_t)b * HW + off) : z4;
+                *reinterpret_cast<float4*>(md_lds + qoff) = make_float4(m.x * v.x, m.y * v.y, m.z * v.z, m.w * v.w);
+            }
         }
     }
 
@@ -216,15 +221,18 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
             // traffic, no bank conflicts).  Only the lanes at the ends of a strip row (and wave lanes 0 / 63)
             // fetch their halo from LDS, in two exec-masked blocks.
             float win[NQ + 2 * R][WIN];
-            const float* rowp[NQ + 2 * R];
+            // rows r0 .. r0+NQ-1+2R of the depth region; only quads below the weight region (NQ > 1, never
+            // computed) can point past its last row, so clamp those.
+            auto row_ptr = [&](int rr) -> const float* {
+                int drow = r0 + rr;
+                if (NQ > 1) drow = drow < dr ? drow : dr - 1;
+                return cur + drow * ls + cb;
+            };
 #pragma unroll
             for (int rr = 0; rr < NQ + 2 * R; ++rr) {
-                int drow = r0 + rr;
-                drow = drow < dr ? drow : dr - 1;
-                rowp[rr] = cur + drow * ls + cb;
                 // volatile: keep this ONE ds_read_b128.  Left alone, the optimiser re-loads overlapping
                 // dword pairs from LDS (bank-conflicted ds_read2_b32) to feed v_pk_fma_f32 operand pairs.
-                const v4f mid = *(lds_cv4f_ptr)(rowp[rr]);
+                const v4f mid = *(lds_cv4f_ptr)(row_ptr(rr));
                 const float m4[4] = {mid.x, mid.y, mid.z, mid.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
@@ -238,13 +246,13 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
 #pragma unroll
                 for (int rr = 0; rr < NQ + 2 * R; ++rr)
 #pragma unroll
-                    for (int c = 0; c < R; ++c) win[rr][c] = rowp[rr][c - R];
+                    for (int c = 0; c < R; ++c) win[rr][c] = row_ptr(rr)[c - R];
             }
             if (fix_right) {
 #pragma unroll
                 for (int rr = 0; rr < NQ + 2 * R; ++rr)
 #pragma unroll
-                    for (int c = 0; c < R; ++c) win[rr][R + 4 + c] = rowp[rr][4 + c];
+                    for (int c = 0; c < R; ++c) win[rr][R + 4 + c] = row_ptr(rr)[4 + c];
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -262,13 +270,23 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                                 u[e] = fmaf(wreg[i][j][e], win[i + dy + R][e + dx + R], u[e]);
                         }
                     float keep[4];   // value carried to the next step through LDS
+                    float om[4] = {1.f, 1.f, 1.f, 1.f}, md[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (BLEND) {
+                        const int qoff = ((r0 + i) * wq + sx) * 4;
+                        const float4 o4 = *reinterpret_cast<const float4*>(om_lds + qoff);
+                        om[0] = o4.x; om[1] = o4.y; om[2] = o4.z; om[3] = o4.w;
+                        if (BLEND == CSPN_BLEND_SPARSE) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(md_lds + qoff);
+                            md[0] = m4.x; md[1] = m4.y; md[2] = m4.z; md[3] = m4.w;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (BLEND == CSPN_BLEND_SPARSE) {
-                            u[e] = (1.f - mreg[i][e]) * u[e] + mreg[i][e] * d0reg[i][e];
+                            u[e] = om[e] * u[e] + md[e];          // (1-m) u + m d0     CSPN_new.py:90
                             keep[e] = u[e];
                         } else if (BLEND == CSPN_BLEND_PREMASK) {
-                            keep[e] = (1.f - mreg[i][e]) * u[e];
+                            keep[e] = om[e] * u[e];
                         } else {
                             keep[e] = u[e];
                         }
@@ -598,7 +616,7 @@ struct Launch {
 };
 
 // Geometry of one fused launch.  Returns false if (plan, S) does not fit the machine limits.
-bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, int threads, Launch* L) {
+bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, int threads, int blend, Launch* L) {
     const int R = K / 2;
     if (tw <= 0 || th <= 0 || (tw & 3) || nq <= 0) return false;
     PropArgs& a = L->a;
@@ -613,7 +631,8 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
     a.dr = a.wr + 2 * R;
     a.ls = 4 * a.wq + 8;
     if ((long)a.wq * ceil_div(a.wr, nq) > threads) return false;
-    L->lds_bytes = (size_t)2 * a.dr * a.ls * sizeof(float);
+    const int blend_planes = blend == CSPN_BLEND_SPARSE ? 2 : (blend == CSPN_BLEND_PREMASK ? 1 : 0);
+    L->lds_bytes = ((size_t)2 * a.dr * a.ls + (size_t)blend_planes * a.wr * 4 * a.wq) * sizeof(float);
     if (L->lds_bytes > 160 * 1024) return false;
     L->grid = B * a.tiles_x * a.tiles_y;
     L->threads = threads;
@@ -771,7 +790,7 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
         }
         if (vec) {
             Launch L;
-            if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, &L))
+            if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, blend, &L))
                 return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
                             p.quads_per_thread, p.threads);
             L.a.w = w; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
@@ -818,7 +837,7 @@ int cspn_plan_resolve(int K, int B, int H, int W, int T, int keep_history, const
     if (!resolved->force_scalar) {
         Launch L;
         if (!make_geometry(K, B, H, W, resolved->steps_per_launch, resolved->tile_w, resolved->tile_h,
-                           resolved->quads_per_thread, resolved->threads, &L))
+                           resolved->quads_per_thread, resolved->threads, CSPN_BLEND_SPARSE /* worst-case LDS */, &L))
             return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, resolved->steps_per_launch,
                         resolved->tile_w, resolved->tile_h, resolved->quads_per_thread, resolved->threads);
     }
