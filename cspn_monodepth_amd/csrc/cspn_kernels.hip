@@ -90,7 +90,8 @@ __device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
 // the fused propagation kernel
 // ------------------------------------------------------------------------------------------------
 struct PropArgs {
-    const void* w;       // [B,NT,H,W]
+    const void* w;       // [B,NT,H,W] tap planes, or (WSRC=1) the guidance tensor itself
+    long g_bs, g_cs;     // WSRC=1: guidance batch / channel strides in elements
     const void* d_in;    // [B,H,W]
     void* d_out;         // [B,H,W] state after the last fused step (may be null when hist != null)
     void* hist;          // null, or plane s-1 (stride B*H*W) receives the state after fused step s
@@ -107,8 +108,13 @@ struct PropArgs {
 // 64 VGPRs (8 waves/SIMD, i.e. 8/4/2 workgroups of 256/512/1024 threads per CU); the others take what they need.
 template <int K, int NQ> struct MinWaves { static constexpr int value = (K == 3 && NQ == 1) ? 8 : 1; };
 
-template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND>
+// WSRC = 0: weights are read from prepared tap planes.  WSRC = 1 (3x3 only): the launch derives them from the
+// raw guidance itself — |g| of the 8 shifted channels, their sum, the IEEE divisions (exactly the arithmetic of
+// cspn3_prepare_kernel, CSPN_new.py:29-70/:124-127) — so inference needs no prepare pass and never
+// materialises the 8 weight planes (saves 53 MB written + 53 MB re-read per forward at config 2).
+template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND, int WSRC>
 __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_fused(const PropArgs a) {
+    static_assert(WSRC == 0 || K == 3, "on-the-fly weights exist for the 3x3 variant only");
     constexpr int R = K / 2;
     constexpr int NT = K * K - 1;
     constexpr int WIN = 4 + 2 * R;
@@ -138,6 +144,9 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     const int xq = x0 - a.hxw + 4 * sx;        // image x of the quad
     const int yq0 = y0 - a.hyw + r0;           // image y of the first quad
     const bool x_in = (xq >= 0) && (xq < W);   // W % 4 == 0: a quad is fully inside or outside
+    const int lane = tid & 63;
+    const bool fix_left = (sx == 0) || (lane == 0);          // left neighbour quad is not lane-1's
+    const bool fix_right = (sx == wq - 1) || (lane == 63);   // right neighbour quad is not lane+1's
 
     // ---- 1. issue the weight stream first (independent of LDS): NQ x NT 16-byte loads -----------
     float wreg[NQ][NT][4];
@@ -155,10 +164,74 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         if (ok && r >= a.hyw && r < a.hyw + a.th && xq >= x0 && xq < x0 + a.tw) interior |= 1u << i;
         const size_t off = (size_t)(ok ? y : 0) * W + (ok ? xq : 0);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (WSRC == 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const float4 v = ok ? ld4(wg + (size_t)j * HW + off) : z4;
-            wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
+            for (int j = 0; j < NT; ++j) {
+                const float4 v = ok ? ld4(wg + (size_t)j * HW + off) : z4;
+                wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
+            }
+        } else {
+            // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j.  The aligned quad of
+            // row y+dy gives three of the four shifted values, the fourth is the neighbouring lane's quad
+            // (DPP wave shift) or, at strip ends, one scalar load.
+            const WT* __restrict__ gq = static_cast<const WT*>(a.w) + (size_t)b * a.g_bs;
+            float left[NT], right[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int lin = j < 4 ? j : j + 1;
+                const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+                const int row = y + dy;
+                const bool rok = ok && row >= 0 && row < H;
+                const WT* src = gq + (size_t)(7 - j) * a.g_cs + (size_t)(rok ? row : 0) * W;
+                const float4 v = rok ? ld4(src + xq) : z4;
+                wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
+                left[j] = 0.f; right[j] = 0.f;
+                if (dx < 0) left[j] = dpp_from_prev_lane(v.w);
+                if (dx > 0) right[j] = dpp_from_next_lane(v.x);
+            }
+            if (fix_left) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int lin = j < 4 ? j : j + 1;
+                    const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+                    if (dx < 0) {
+                        const int row = y + dy;
+                        const bool c = ok && row >= 0 && row < H && xq >= 1;
+                        left[j] = c ? ld1(gq + (size_t)(7 - j) * a.g_cs + (size_t)row * W + xq - 1) : 0.f;
+                    }
+                }
+            }
+            if (fix_right) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int lin = j < 4 ? j : j + 1;
+                    const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+                    if (dx > 0) {
+                        const int row = y + dy;
+                        const bool c = ok && row >= 0 && row < H && xq + 4 < W;
+                        right[j] = c ? ld1(gq + (size_t)(7 - j) * a.g_cs + (size_t)row * W + xq + 4) : 0.f;
+                    }
+                }
+            }
+            // a_j[e] = |g_{7-j}[p_e + off_j]|
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int lin = j < 4 ? j : j + 1;
+                const int dx = lin % 3 - 1;
+                const float q0 = wreg[i][j][0], q1 = wreg[i][j][1], q2 = wreg[i][j][2], q3 = wreg[i][j][3];
+                if (dx < 0) { wreg[i][j][0] = fabsf(left[j]); wreg[i][j][1] = fabsf(q0); wreg[i][j][2] = fabsf(q1); wreg[i][j][3] = fabsf(q2); }
+                else if (dx > 0) { wreg[i][j][0] = fabsf(q1); wreg[i][j][1] = fabsf(q2); wreg[i][j][2] = fabsf(q3); wreg[i][j][3] = fabsf(right[j]); }
+                else { wreg[i][j][0] = fabsf(q0); wreg[i][j][1] = fabsf(q1); wreg[i][j][2] = fabsf(q2); wreg[i][j][3] = fabsf(q3); }
+            }
+            // S in the reference's channel order k = 0..7 (tap 7..0), then true division; 0 for padding quads
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float S = wreg[i][7][e];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) S += wreg[i][7 - k][e];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wreg[i][j][e] = ok ? wreg[i][j][e] / S : 0.f;
+            }
         }
         if (BLEND && r < wr) {
             const float4 m = ok ? sgn4(ld4(spg + off)) : z4;
@@ -207,9 +280,6 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     // ---- 3. S propagation steps in LDS ------------------------------------------------------------
     const bool active = (r0 < wr);
     const int cb = 4 + 4 * sx;
-    const int lane = tid & 63;
-    const bool fix_left = (sx == 0) || (lane == 0);          // left neighbour quad is not lane-1's
-    const bool fix_right = (sx == wq - 1) || (lane == 63);   // right neighbour quad is not lane+1's
     DT* __restrict__ dout = a.d_out ? static_cast<DT*>(a.d_out) + (size_t)b * HW : nullptr;
     DT* __restrict__ hist = a.hist ? static_cast<DT*>(a.hist) + (size_t)b * HW : nullptr;
 
@@ -699,11 +769,11 @@ void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const csp
     if (p->tile_h > hmax) p->tile_h = hmax;
 }
 
-template <int K, int NQ, int NTHREADS, typename WT, typename DT>
+template <int K, int NQ, int NTHREADS, typename WT, typename DT, int WSRC>
 int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 #define CSPN_LAUNCH(BL)                                                                               \
     do {                                                                                              \
-        auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL>;                                     \
+        auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL, WSRC>;                               \
         if (L.lds_bytes > 64 * 1024)                                                                  \
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes)); \
@@ -721,9 +791,21 @@ int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 }
 
 template <int K, typename WT, typename DT>
-int launch_fused(const Launch& L, int blend, hipStream_t st) {
+int launch_fused(const Launch& L, int blend, int wsrc, hipStream_t st) {
+    if constexpr (K == 3) {
+        if (wsrc) {      // on-the-fly weights: one- and two-quad instances only
+#define CSPN_CASE_G(NQV, NTV) \
+    if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT, 1>(L, blend, st)
+            CSPN_CASE_G(1, 256); CSPN_CASE_G(2, 256); CSPN_CASE_G(1, 512); CSPN_CASE_G(2, 512);
+            CSPN_CASE_G(1, 1024); CSPN_CASE_G(2, 1024);
+#undef CSPN_CASE_G
+            return fail("no from-guidance kernel instance for quads_per_thread=%d threads=%d", L.nq, L.threads);
+        }
+    } else if (wsrc) {
+        return fail("on-the-fly weights exist for K=3 only");
+    }
 #define CSPN_CASE(NQV, NTV) \
-    if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT>(L, blend, st)
+    if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT, 0>(L, blend, st)
     if constexpr (K == 3) {
         CSPN_CASE(1, 256); CSPN_CASE(2, 256); CSPN_CASE(4, 256); CSPN_CASE(8, 256);
         CSPN_CASE(1, 512); CSPN_CASE(2, 512); CSPN_CASE(4, 512); CSPN_CASE(1, 1024); CSPN_CASE(2, 1024);
@@ -758,7 +840,8 @@ int launch_scalar(const void* w, const void* din, void* dout, const void* sp, co
 
 template <int K, typename WT, typename DT>
 int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
-                    int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st) {
+                    int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st,
+                    int wsrc = 0, long g_bs = 0, long g_cs = 0) {
     const size_t plane_bytes = (size_t)B * H * W * sizeof(DT);
     if (T == 0) {
         if (out) HIP_OK(hipMemcpyAsync(out, d0, plane_bytes, hipMemcpyDeviceToDevice, st));
@@ -793,11 +876,13 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
             if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, blend, &L))
                 return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
                             p.quads_per_thread, p.threads);
-            L.a.w = w; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
+            L.a.w = w; L.a.g_bs = g_bs; L.a.g_cs = g_cs; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
             L.a.d_out = history ? nullptr : dst;
             L.a.hist = hist_base;
-            if (!launch_fused<K, WT, DT>(L, blend, st)) return 0;
+            if (!launch_fused<K, WT, DT>(L, blend, wsrc, st)) return 0;
         } else {
+            if (wsrc) return fail("from-guidance propagation needs W %% 4 == 0 and 16-byte aligned tensors; "
+                                  "use cspn3_prepare + cspn_propagate");
             if (!launch_scalar<K, WT, DT>(w, src, dst, sparse, d0, B, H, W, blend, st)) return 0;
         }
         src = dst;
@@ -905,6 +990,23 @@ int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* spars
         case 7: return propagate_k<7>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
         default: return fail("cspn_propagate: unsupported K=%d (3, 5, 7)", K);
     }
+}
+
+int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, const void* d0,
+                                  const void* sparse, void* out, void* history, void* work, int d_dtype, int B, int H,
+                                  int W, int T, int blend, const cspn_plan* plan, cspn_stream_t stream) {
+    if (!guidance || !d0 || B <= 0 || H <= 0 || W <= 0 || T < 0) return fail("cspn3_propagate_from_guidance: bad arguments");
+    if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn3_propagate_from_guidance: blend %d", blend);
+    if (blend != CSPN_BLEND_NONE && !sparse) return fail("cspn3_propagate_from_guidance: blend needs sparse");
+    if ((cs & 3) || (bs & 3)) return fail("cspn3_propagate_from_guidance: guidance strides must be multiples of 4 elements");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_dtype == CSPN_F32 && d_dtype == CSPN_F32)
+        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs);
+    if (g_dtype == CSPN_F16 && d_dtype == CSPN_F16)
+        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs);
+    if (g_dtype == CSPN_F16 && d_dtype == CSPN_F32)
+        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs);
+    return fail("cspn3_propagate_from_guidance: unsupported dtypes g=%d d=%d", g_dtype, d_dtype);
 }
 
 int cspn_transpose_weights(const void* w, void* wT, int w_dtype, int B, int H, int W, int K, cspn_stream_t stream) {

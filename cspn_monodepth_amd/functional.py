@@ -33,6 +33,16 @@ def resolve_plan(K, B, H, W, T, keep_history=False, plan=None):
     return {name: int(getattr(out, name)) for name, _ in cspn_plan._fields_}
 
 
+_FROM_GUIDANCE = False   # see set_from_guidance
+
+
+def set_from_guidance(enabled):
+    """Route no-grad 3x3 forwards through cspn3_propagate_from_guidance (saves the [B,8,H,W] weight buffer:
+    53 MB at config 2; bit-identical results; ~10 % slower than prepare + propagate on MI355X)."""
+    global _FROM_GUIDANCE
+    _FROM_GUIDANCE = bool(enabled)
+
+
 _TUNED = {}          # autotune cache: problem key -> plan dict
 _NQ_THREADS = {3: ((1, 256), (2, 256), (4, 256), (1, 512), (2, 512), (4, 512), (1, 1024), (2, 1024)),
                5: ((1, 256), (2, 256), (3, 256), (1, 512)),
@@ -246,6 +256,54 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
     return out, None
 
 
+def from_guidance_supported(guidance, d0, sparse):
+    """The fused prepare+propagate entry needs whole, 16-byte aligned quads (W % 4 == 0)."""
+    W = guidance.shape[-1]
+    tensors = [t for t in (guidance, d0, sparse) if t is not None]
+    return (W % 4 == 0 and guidance.is_contiguous() and guidance.stride(0) % 4 == 0 and guidance.stride(1) % 4 == 0
+            and all(t.data_ptr() % 16 == 0 for t in tensors))
+
+
+def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, plan=None):
+    """3x3 variant without a prepare pass: every launch derives the normalised weights from `guidance`
+    (cspn3_propagate_from_guidance).  Same results, bit for bit, as cspn3_prepare + propagate."""
+    dev = _require_device(guidance, d0, sparse)
+    B, C, H, W = guidance.shape
+    if C < 8:
+        raise ValueError("guidance must have >= 8 channels")
+    g = guidance if guidance.is_contiguous() else guidance.contiguous()
+    if not (d0.is_contiguous() and (sparse is None or sparse.is_contiguous())):
+        raise ValueError("propagate_from_guidance: tensors must be contiguous")
+    L = _lib.lib()
+    T = int(T)
+    hist = out = work = None
+    if isinstance(plan, str):
+        plan = None if plan != "auto" else _TUNED.get(("g3", B, H, W, T, g.dtype, d0.dtype, int(blend), dev.index))
+    if keep_history and T > 0:
+        hist = torch.empty((T, B, H, W), dtype=d0.dtype, device=dev)
+    else:
+        out = torch.empty((B, H, W), dtype=d0.dtype, device=dev)
+        nbytes = L.cspn_propagate_workspace_bytes(B, H, W, T, _dt(d0), 0)
+        if nbytes:
+            work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    log = _EVENT_LOG
+    with torch.cuda.device(dev):
+        if log is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(dev))
+        ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(d0), _p(sparse), _p(out),
+                                             _p(hist), _p(work), _dt(d0), B, H, W, T, int(blend),
+                                             _plan_ptr(3, plan), _stream(dev))
+        if log is not None:
+            ev1.record(torch.cuda.current_stream(dev))
+            S = resolve_plan(3, B, H, W, T, keep_history, plan)["steps_per_launch"]
+            log.append((ev0, ev1, -(-T // max(S, 1)), S))
+    _lib.check(ok, "cspn3_propagate_from_guidance")
+    if hist is not None:
+        return hist[T - 1], hist
+    return out, None
+
+
 def transpose_weights(w, K):
     dev = _require_device(w)
     B, NT, H, W = w.shape
@@ -292,9 +350,14 @@ class CSPN3Function(torch.autograd.Function):
         if d0.dtype != guidance.dtype or (sp is not None and sp.dtype != guidance.dtype):
             raise TypeError("guidance / blur_depth / sparse_depth must share one dtype")
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        blend = BLEND_SPARSE if sp is not None else BLEND_NONE
+        if not need_grad and _FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp):
+            # opt-in (set_from_guidance): no prepare pass and no 8-plane weight buffer; measured slower on
+            # MI355X (the per-launch divisions over the halo region cost more than the prepare pass saves)
+            out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan)
+            return out.unsqueeze(1)
         w8, S, g = cspn3_prepare(guidance, want_s=need_grad)
-        out, hist = propagate(w8, d0, sp, 3, prop_time, BLEND_SPARSE if sp is not None else BLEND_NONE,
-                              keep_history=need_grad, plan=plan)
+        out, hist = propagate(w8, d0, sp, 3, prop_time, blend, keep_history=need_grad, plan=plan)
         if need_grad:
             ctx.save_for_backward(g, w8, S, d0, sp, hist)
             ctx.prop_time, ctx.plan = int(prop_time), plan

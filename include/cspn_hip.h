@@ -94,6 +94,16 @@ int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* spars
                    void* history, void* work, int d_dtype, int B, int H, int W, int K, int T,
                    int blend, const cspn_plan* plan, cspn_stream_t stream);
 
+/* 3x3 variant, inference: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
+ * weights from the raw guidance (same arithmetic, bit-identical results), so the 8 weight planes are never
+ * written to or re-read from HBM.  Arguments as cspn3_prepare (guidance, strides) + cspn_propagate.
+ * Needs W % 4 == 0 and 16-byte aligned tensors (returns 0 otherwise: use the two-call form).
+ * blend: CSPN_BLEND_NONE or CSPN_BLEND_SPARSE.  Replaces all of CSPN_new.py:29-92 for a forward pass. */
+int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
+                                  const void* d0, const void* sparse, void* out, void* history, void* work,
+                                  int d_dtype, int B, int H, int W, int T, int blend, const cspn_plan* plan,
+                                  cspn_stream_t stream);
+
 /* ---- backward ---------------------------------------------------------------------------------- */
 
 /* wT[b][j][q] = w[b][NT-1-j][q+off_j] (0 outside): weights of the transposed stencil, so that the

@@ -137,6 +137,44 @@ def test_size_independent_properties():
         assert torch.equal(m(g2, d1), o1)
 
 
+@pytest.mark.parametrize("plan", [None, dict(steps_per_launch=1, tile_w=32, tile_h=32, quads_per_thread=1, threads=256),
+                                  dict(steps_per_launch=5, tile_w=44, tile_h=30, quads_per_thread=2, threads=512),
+                                  dict(steps_per_launch=8, tile_w=40, tile_h=27, quads_per_thread=1, threads=1024)],
+                         ids=["default", "s1", "s5nq2", "s8"])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_from_guidance_equals_prepare_plus_propagate(plan, sparse, c_oracle):
+    """The inference entry (weights derived inside every launch) is bit-identical to the two-call form and
+    matches the oracle; shapes include image borders inside tiles, a narrow image and a 1-row image."""
+    from cspn_monodepth_amd import functional as F
+    for (B, H, W, T) in ((3, 100, 148, 24), (2, 37, 8, 7), (1, 1, 12, 3), (1, 5, 4, 6)):
+        g, d, s = c_oracle.synthetic_inputs(17, B, H, W, 12, max(2, H * W // 50) if sparse else None)
+        gt, dt, st = dev(g), dev(d)[:, 0].contiguous(), (dev(s)[:, 0].contiguous() if sparse else None)
+        blend = F.BLEND_SPARSE if sparse else F.BLEND_NONE
+        try:
+            F.resolve_plan(3, B, H, W, T, False, plan)
+        except RuntimeError:
+            continue                                   # plan does not fit this tiny shape
+        with torch.no_grad():
+            w8, _, _ = F.cspn3_prepare(gt)
+            a, _ = F.propagate(w8, dt, st, 3, T, blend, plan=plan)
+            b, _ = F.propagate_from_guidance(gt, dt, st, T, blend, plan=plan)
+            _, hist = F.propagate_from_guidance(gt, dt, st, T, blend, keep_history=True, plan=plan)
+        assert torch.equal(a, b) and torch.equal(hist[T - 1], a)
+        want = c_oracle.cspn3_forward(g, d, s if sparse else None, T)[:, 0]
+        assert rel_err(b.cpu().numpy(), want) <= REL_TOL
+    # module-level switch
+    g, d, s = c_oracle.synthetic_inputs(18, 2, 40, 52, 12, 50)
+    m = pkg.CSPN_new.AffinityPropagate(9, 3, plan=plan)
+    with torch.no_grad():
+        ref = m(dev(g), dev(d), dev(s) if sparse else None)
+        F.set_from_guidance(True)
+        try:
+            alt = m(dev(g), dev(d), dev(s) if sparse else None)
+        finally:
+            F.set_from_guidance(False)
+    assert torch.equal(ref, alt)
+
+
 def test_strided_and_noncontiguous_inputs(c_oracle):
     g, d, s = c_oracle.synthetic_inputs(4, 2, 20, 24, 12, 40)
     want = c_oracle.cspn3_forward(g, d, s, 5)

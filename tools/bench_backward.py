@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Forward+backward timing of the 3x3 module (developer tool): training-shaped use of the engine."""
+import argparse, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cspn_monodepth_amd as pkg
+from tools.tune import timed
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=24)
+ap.add_argument("--H", type=int, default=228)
+ap.add_argument("--W", type=int, default=304)
+ap.add_argument("--T", type=int, default=24)
+ap.add_argument("--reps", type=int, default=20)
+args = ap.parse_args()
+dev = "cuda"
+B, H, W, T = args.batch, args.H, args.W, args.T
+g = torch.randn(B, 12, H, W, device=dev, requires_grad=True)
+d = (torch.rand(B, 1, H, W, device=dev) * 10).requires_grad_(True)
+s = (d.detach() * (torch.rand(B, 1, H, W, device=dev) < 0.0072))
+cot = torch.randn(B, 1, H, W, device=dev)
+m = pkg.CSPN_new.AffinityPropagate(T, 3)
+
+def fwd_bwd(sp):
+    g.grad = None; d.grad = None
+    out = m(g, d, sp)
+    out.backward(cot)
+
+for name, sp in (("no sparse", None), ("sparse", s)):
+    with torch.no_grad():
+        t_inf = timed(lambda: m(g, d, sp), args.reps)
+    t_fwd = timed(lambda: m(g, d, sp), args.reps)
+    t_all = timed(lambda: fwd_bwd(sp), args.reps)
+    print("%-9s B=%d %dx%d T=%d: inference fwd %.1f us | training fwd %.1f us | fwd+bwd %.1f us (bwd %.1f us)" % (
+        name, B, W, H, T, t_inf, t_fwd, t_all, t_all - t_fwd))

@@ -11,7 +11,7 @@ for b in re.split(r'remark: Function Name: ', txt)[1:]:
     def g(k):
         m = re.search(k + r': (\d+)', b)
         return int(m.group(1)) if m else -1
-    m = re.search(r'fusedILi(\d)ELi(\d)ELi(\d+)E(\w+?)Li(\d)E', name)
+    m = re.search(r'fusedILi(\d)ELi(\d)ELi(\d+)E(\w+?)Li(\d)ELi(\d)E', name)
     if not m:
         continue
     K, NQ, NT, ty, bl = m.groups()

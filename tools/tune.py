@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--sparse", action="store_true")
     ap.add_argument("--S", default="1,2,3,4,5,6,7,8,9,10,12")
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--from-guidance", action="store_true", help="time the fused prepare+propagate entry (K=3)")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -93,7 +94,10 @@ def main():
                             plan = dict(steps_per_launch=S, tile_w=tw, tile_h=th, quads_per_thread=nq, threads=threads)
                             try:
                                 F.resolve_plan(K, B, H, W, T, False, plan)
-                                us = timed(lambda: F.propagate(w, d0, sp, K, T, blend, plan=plan), args.reps, 1)
+                                if args.from_guidance:
+                                    us = timed(lambda: F.propagate_from_guidance(g, d0, sp, T, blend, plan=plan), args.reps, 1)
+                                else:
+                                    us = timed(lambda: F.propagate(w, d0, sp, K, T, blend, plan=plan), args.reps, 1)
                             except RuntimeError:
                                 continue
                             rows.append(dict(plan, us=us, alg_GBs=alg / us / 1e3))
