@@ -25,7 +25,8 @@ EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
     "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn3_propagate_from_guidance",
     "cspn_transpose_weights",
-    "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn_metrics_accumulate",
+    "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
+    "cspn_pac_backward_tail", "cspn_metrics_accumulate",
 )
 
 
@@ -73,6 +74,8 @@ def _declare(lib):
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
     lib.cspn_pac_grad_guided.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.cspn3_backward_tail.argtypes = [vp, vp, vp, vp, vp, cl, cl, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.cspn_pac_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, ci, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -314,26 +314,37 @@ def transpose_weights(w, K):
     return wT
 
 
-def _backward_common(w, K, T, d0, dhist, sparse, grad_out, plan):
-    """Shared reverse sweep: returns (gw [B,NT,H,W] f32, gd0 [B,H,W] f32)."""
+def _reverse_sweep(w, K, T, sparse, grad_out, plan):
+    """G_T = dL/dout, G_t = stencil^T((1-m) G_{t+1}): the forward kernel on the transposed weights.
+    Returns ghist [T+1,B,H,W] f32 in backward order (ghist[s] = G_{T-s})."""
     dev = w.device
     B, NT, H, W = w.shape
-    L = _lib.lib()
     ghist = torch.empty((T + 1, B, H, W), dtype=torch.float32, device=dev)
     ghist[0].copy_(grad_out.reshape(B, H, W))
-    sp32 = None if sparse is None else sparse.float()
     if T > 0:
+        sp32 = None if sparse is None else sparse.float()
         wT = transpose_weights(w, K)
         with torch.cuda.device(dev):
-            ok = L.cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None, CSPN_F32,
-                                  B, H, W, int(K), T, BLEND_PREMASK if sparse is not None else BLEND_NONE,
-                                  _plan_ptr(K, plan), _stream(dev))
+            ok = _lib.lib().cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
+                                           CSPN_F32, B, H, W, int(K), T,
+                                           BLEND_PREMASK if sparse is not None else BLEND_NONE,
+                                           _plan_ptr(K, plan), _stream(dev))
         _lib.check(ok, "cspn_propagate(backward)")
-    gw = torch.empty((B, NT, H, W), dtype=torch.float32, device=dev)
-    gd0 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        ok = L.cspn_grad_weights(_p(d0), _p(dhist), _p(ghist), _p(sparse), _p(gw), _p(gd0), _dt(d0),
-                                 B, H, W, int(K), T, _stream(dev))
+    return ghist
+
+
+def _tail_vector_ok(W, *tensors):
+    return W % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def _grad_weights(w, K, T, d0, dhist, sparse, ghist):
+    """Unfused dL/dw + dL/dd0 (any shape / alignment)."""
+    B, NT, H, W = w.shape
+    gw = torch.empty((B, NT, H, W), dtype=torch.float32, device=w.device)
+    gd0 = torch.empty((B, H, W), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        ok = _lib.lib().cspn_grad_weights(_p(d0), _p(dhist), _p(ghist), _p(sparse), _p(gw), _p(gd0), _dt(d0),
+                                          B, H, W, int(K), T, _stream(w.device))
     _lib.check(ok, "cspn_grad_weights")
     return gw, gd0
 
@@ -369,15 +380,23 @@ class CSPN3Function(torch.autograd.Function):
         g, w8, S, d0, sp, hist = ctx.saved_tensors
         B, C, H, W = g.shape
         T = ctx.prop_time
-        go = grad_out.contiguous().float()
-        gw, gd0 = _backward_common(w8, 3, T, d0, hist, sp, go, ctx.plan)
-        gg = None
-        if ctx.needs_input_grad[0]:
-            gg = torch.empty_like(g)
+        L = _lib.lib()
+        ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan)
+        gg = torch.empty_like(g)
+        if _tail_vector_ok(W, g, w8, S, d0, sp, hist, gg) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
+            gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)
             with torch.cuda.device(g.device):
-                ok = _lib.lib().cspn3_grad_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), C, _p(w8), _dt(w8),
-                                                    _p(S), _p(gw), _p(gg), B, H, W, _stream(g.device))
+                ok = L.cspn3_backward_tail(_p(d0), _p(hist), _p(ghist), _p(sp), _p(g), g.stride(0), g.stride(1), C,
+                                           _p(w8), _p(S), _p(gg), _p(gd0), _dt(g), B, H, W, T, _stream(g.device))
+            _lib.check(ok, "cspn3_backward_tail")
+        else:
+            gw, gd0 = _grad_weights(w8, 3, T, d0, hist, sp, ghist)
+            with torch.cuda.device(g.device):
+                ok = L.cspn3_grad_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), C, _p(w8), _dt(w8),
+                                           _p(S), _p(gw), _p(gg), B, H, W, _stream(g.device))
             _lib.check(ok, "cspn3_grad_guidance")
+        if not ctx.needs_input_grad[0]:
+            gg = None
         gd = gd0.to(d0.dtype).reshape(ctx.in_shape) if ctx.needs_input_grad[1] else None
         return gg, gd, None, None, None
 
@@ -408,14 +427,23 @@ class PACFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         wk, d0, sp, hist = ctx.saved_tensors
         B, NT, H, W = wk.shape
-        gw, gx0 = _backward_common(wk, ctx.K, ctx.prop_time, d0, hist, sp, grad_out.contiguous().float(), ctx.plan)
-        gg = None
-        if ctx.needs_input_grad[1]:
-            gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
+        K, T = ctx.K, ctx.prop_time
+        L = _lib.lib()
+        ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan)
+        gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
+        if _tail_vector_ok(W, wk, d0, sp, hist, gg):
+            gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
             with torch.cuda.device(wk.device):
-                ok = _lib.lib().cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, ctx.K,
-                                                     _stream(wk.device))
+                ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
+                                              _dt(wk), B, H, W, K, T, _stream(wk.device))
+            _lib.check(ok, "cspn_pac_backward_tail")
+        else:
+            gw, gx0 = _grad_weights(wk, K, T, d0, hist, sp, ghist)
+            with torch.cuda.device(wk.device):
+                ok = L.cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, K, _stream(wk.device))
             _lib.check(ok, "cspn_pac_grad_guided")
+        if not ctx.needs_input_grad[1]:
+            gg = None
         gx = gx0.to(ctx.x_dtype).unsqueeze(1) if ctx.needs_input_grad[0] else None
         return gx, gg, None, None, None, None
 

@@ -131,6 +131,19 @@ int cspn3_grad_guidance(const void* guidance, int g_dtype, long g_batch_stride, 
 int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* grad_guided, int g_dtype,
                          int B, int H, int W, int K, cspn_stream_t stream);
 
+/* Fused backward tails (vector path: W % 4 == 0, 16-byte aligned tensors; return 0 otherwise so the caller uses
+ * the three-call form above).  One pass over the histories accumulates dL/dw in registers and applies the
+ * guidance / softmax epilogue there, so dL/dw never goes to HBM:
+ *   cspn3_backward_tail    = cspn_grad_weights + cspn3_grad_guidance   (all tensors of one dtype)
+ *   cspn_pac_backward_tail = cspn_grad_weights + cspn_pac_grad_guided */
+int cspn3_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+                        const void* guidance, long g_batch_stride, long g_chan_stride, int C, const void* w8,
+                        const float* s, void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T,
+                        cspn_stream_t stream);
+int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+                           const void* wk, void* grad_guided, float* gd0, int d_dtype, int w_dtype,
+                           int B, int H, int W, int K, int T, cspn_stream_t stream);
+
 /* ---- evaluation (libs/metrics.py:49-83, base_model.py:28-73) ------------ */
 
 /* acc[nslots][10] (f64, zero-initialised by the caller): row (block % nslots) += masked sums over target>0 of
