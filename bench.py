@@ -36,6 +36,8 @@ WORKLOADS = {
                 name="NYU-v2 304x228 batch=24, 24-iter 3x3 CSPN (BASELINE config 2)"),
     "kitti": dict(B=8, H=352, W=1216, K=3, T=24, dtype="f32", C=12,
                   name="KITTI 1216x352 batch=8 sharded over the ranks, 24-iter 3x3 CSPN (BASELINE config 4)"),
+    "pac5f32": dict(B=24, H=228, W=304, K=5, T=12, dtype="f32", C=24,
+                    name="NYU-v2 304x228 batch=24, 5x5 softmax affinity, 12 iters, fp32"),
     "pac5": dict(B=24, H=228, W=304, K=5, T=12, dtype="f16", C=24,
                  name="NYU-v2 304x228 batch=24, 5x5 softmax affinity, 12 iters, fp16 (BASELINE config 3)"),
 }
@@ -131,6 +133,7 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
     ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed steady-state pre-warm-up before the W warm-up steps")
     ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
     args = ap.parse_args()
 
@@ -191,18 +194,31 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        # untimed pre-warm-up (on top of the W warm-up steps): lets the caching allocator, the lazily created
+        # HIP modules and the GPU clocks settle, so that short runs (small K/W) measure the same steady state
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_s:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
+        pkg.evaluation.all_gather_metric_sums(sums)   # untimed: first use loads the reduction kernels / sets up RCCL
         sums.zero_()
-        events = []
+        events = F.EventLog(args.steps)
         F.set_event_log(events)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        t_loop = time.perf_counter()
         total, per_rank = pkg.evaluation.all_gather_metric_sums(sums)  # the only collective: 10 float64 per rank
+        t_gather = time.perf_counter()
         fence()
         t1 = time.perf_counter()
+        if os.environ.get("BENCH_DEBUG") and rank == 0:
+            print("debug: host loop %.2f ms, gather call %.2f ms, final fence %.2f ms" % (
+                (t_loop - t0) * 1e3, (t_gather - t_loop) * 1e3, (t1 - t_gather) * 1e3), file=sys.stderr)
         F.set_event_log(None)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if world > 1:
@@ -231,14 +247,14 @@ def main():
     if rank == 0 and S != 1 and K == 3:
         p1 = dict(steps_per_launch=1, tile_w=32, tile_h=29 if wl["H"] == 228 else 32, quads_per_thread=1, threads=256)
         m1 = pkg.CSPN_new.AffinityPropagate(T, 3, plan=p1)
-        ev1 = []
+        n1 = max(10, args.steps // 4)
+        ev1 = F.EventLog(n1)
         with torch.no_grad():
             for _ in range(5):
                 m1(g, d, s)
             F.set_event_log(ev1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n1 = max(10, args.steps // 4)
             for _ in range(n1):
                 m1(g, d, s)
             torch.cuda.synchronize()

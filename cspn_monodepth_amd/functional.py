@@ -15,11 +15,31 @@ from . import _lib
 from ._lib import BLEND_NONE, BLEND_PREMASK, BLEND_SPARSE, CSPN_F16, CSPN_F32, cspn_plan
 
 _DEFAULT_PLANS = {}   # K -> dict, set by set_default_plan (e.g. from a tuning run)
-_EVENT_LOG = None     # when a list: propagate() appends (start_event, end_event, n_launches, steps_per_launch)
+_EVENT_LOG = None     # when an EventLog: propagate() records (start_event, end_event, n_launches, steps_per_launch)
+
+
+class EventLog(list):
+    """bench.py hook: HIP events recorded on the launch stream around every propagation loop.
+
+    Event objects are created (and recorded once, which is what actually allocates them) up front: creating
+    them inside a timed region costs ~100 us each for the first few hundred."""
+
+    def __init__(self, n_pairs=0):
+        super(EventLog, self).__init__()
+        self.pool = []
+        for _ in range(2 * int(n_pairs)):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.pool.append(ev)
+        self.plan_cache = {}
+
+    def pair(self):
+        if len(self.pool) >= 2:
+            return self.pool.pop(), self.pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
 def set_event_log(log):
-    """bench.py hook: HIP events recorded on the launch stream around every propagation loop."""
     global _EVENT_LOG
     _EVENT_LOG = log
 
@@ -150,6 +170,23 @@ def _require_device(*tensors):
     return dev
 
 
+class _device_guard(object):
+    """`with torch.cuda.device(dev)` only when `dev` is not already current (the common case costs ~nothing)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -184,7 +221,7 @@ def cspn3_prepare(guidance, want_s=False, w_dtype=None):
     w_dtype = g.dtype if w_dtype is None else w_dtype
     w8 = torch.empty((B, 8, H, W), dtype=w_dtype, device=dev)
     S = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_s else None
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         ok = _lib.lib().cspn3_prepare(_p(g), _dt(g), g.stride(0), g.stride(1), B, H, W, _p(w8), _dt(w8), _p(S),
                                       _stream(dev))
     _lib.check(ok, "cspn3_prepare")
@@ -205,7 +242,7 @@ def pac_prepare(guided, w_dtype=None):
     if w_dtype != g.dtype:
         raise TypeError("pac_prepare: weight dtype must equal guided dtype")
     wk = torch.empty((B, C, H, W), dtype=w_dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         ok = _lib.lib().cspn_pac_prepare(_p(g), _dt(g), B, H, W, K, _p(wk), _dt(wk), _stream(dev))
     _lib.check(ok, "cspn_pac_prepare")
     return wk, K
@@ -240,15 +277,18 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
         if nbytes:
             work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     log = _EVENT_LOG
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         if log is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0, ev1 = log.pair()
             ev0.record(torch.cuda.current_stream(dev))
         ok = L.cspn_propagate(_p(w), _dt(w), _p(d0), _p(sparse), _p(out), _p(hist), _p(work), _dt(d0),
                               B, H, W, int(K), T, int(blend), _plan_ptr(K, plan), _stream(dev))
         if log is not None:
             ev1.record(torch.cuda.current_stream(dev))
-            S = resolve_plan(K, B, H, W, T, keep_history, plan)["steps_per_launch"]
+            key = (K, B, H, W, T, keep_history, id(plan))
+            if key not in log.plan_cache:
+                log.plan_cache[key] = resolve_plan(K, B, H, W, T, keep_history, plan)["steps_per_launch"]
+            S = log.plan_cache[key]
             log.append((ev0, ev1, -(-T // max(S, 1)), S))
     _lib.check(ok, "cspn_propagate")
     if hist is not None:
@@ -287,9 +327,9 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
         if nbytes:
             work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     log = _EVENT_LOG
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         if log is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0, ev1 = log.pair()
             ev0.record(torch.cuda.current_stream(dev))
         ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(d0), _p(sparse), _p(out),
                                              _p(hist), _p(work), _dt(d0), B, H, W, T, int(blend),
@@ -308,7 +348,7 @@ def transpose_weights(w, K):
     dev = _require_device(w)
     B, NT, H, W = w.shape
     wT = torch.empty_like(w)
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         ok = _lib.lib().cspn_transpose_weights(_p(w), _p(wT), _dt(w), B, H, W, int(K), _stream(dev))
     _lib.check(ok, "cspn_transpose_weights")
     return wT
@@ -324,7 +364,7 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan):
     if T > 0:
         sp32 = None if sparse is None else sparse.float()
         wT = transpose_weights(w, K)
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             ok = _lib.lib().cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
                                            CSPN_F32, B, H, W, int(K), T,
                                            BLEND_PREMASK if sparse is not None else BLEND_NONE,
@@ -342,7 +382,7 @@ def _grad_weights(w, K, T, d0, dhist, sparse, ghist):
     B, NT, H, W = w.shape
     gw = torch.empty((B, NT, H, W), dtype=torch.float32, device=w.device)
     gd0 = torch.empty((B, H, W), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _device_guard(w.device):
         ok = _lib.lib().cspn_grad_weights(_p(d0), _p(dhist), _p(ghist), _p(sparse), _p(gw), _p(gd0), _dt(d0),
                                           B, H, W, int(K), T, _stream(w.device))
     _lib.check(ok, "cspn_grad_weights")
@@ -350,6 +390,11 @@ def _grad_weights(w, K, T, d0, dhist, sparse, ghist):
 
 
 # ------------------------------------------------------------------------------------------------ autograd
+class _NoGradCtx(object):
+    """Stand-in ctx for inference calls that skip torch.autograd.Function.apply (saves ~10 us of host time)."""
+    needs_input_grad = (False, False, False, False, False, False)
+
+
 class CSPN3Function(torch.autograd.Function):
     """3x3 variant, forward + hand-written backward (SURVEY.md §3.2 closed form)."""
 
@@ -385,13 +430,13 @@ class CSPN3Function(torch.autograd.Function):
         gg = torch.empty_like(g)
         if _tail_vector_ok(W, g, w8, S, d0, sp, hist, gg) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
             gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)
-            with torch.cuda.device(g.device):
+            with _device_guard(g.device):
                 ok = L.cspn3_backward_tail(_p(d0), _p(hist), _p(ghist), _p(sp), _p(g), g.stride(0), g.stride(1), C,
                                            _p(w8), _p(S), _p(gg), _p(gd0), _dt(g), B, H, W, T, _stream(g.device))
             _lib.check(ok, "cspn3_backward_tail")
         else:
             gw, gd0 = _grad_weights(w8, 3, T, d0, hist, sp, ghist)
-            with torch.cuda.device(g.device):
+            with _device_guard(g.device):
                 ok = L.cspn3_grad_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), C, _p(w8), _dt(w8),
                                            _p(S), _p(gw), _p(gg), B, H, W, _stream(g.device))
             _lib.check(ok, "cspn3_grad_guidance")
@@ -433,13 +478,13 @@ class PACFunction(torch.autograd.Function):
         gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
         if _tail_vector_ok(W, wk, d0, sp, hist, gg):
             gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
-            with torch.cuda.device(wk.device):
+            with _device_guard(wk.device):
                 ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
                                               _dt(wk), B, H, W, K, T, _stream(wk.device))
             _lib.check(ok, "cspn_pac_backward_tail")
         else:
             gw, gx0 = _grad_weights(wk, K, T, d0, hist, sp, ghist)
-            with torch.cuda.device(wk.device):
+            with _device_guard(wk.device):
                 ok = L.cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, K, _stream(wk.device))
             _lib.check(ok, "cspn_pac_grad_guided")
         if not ctx.needs_input_grad[1]:
@@ -451,10 +496,14 @@ class PACFunction(torch.autograd.Function):
 def cspn3_affinity_propagate(guidance, blur_depth, sparse_depth=None, prop_time=24, plan=None):
     """Functional form of CSPN_new.AffinityPropagate.forward (CSPN_new.py:26-92)."""
     _require_device(guidance, blur_depth, sparse_depth)
+    if not (torch.is_grad_enabled() and (guidance.requires_grad or blur_depth.requires_grad)):
+        return CSPN3Function.forward(_NoGradCtx, guidance, blur_depth, sparse_depth, int(prop_time), plan)
     return CSPN3Function.apply(guidance, blur_depth, sparse_depth, int(prop_time), plan)
 
 
 def pac_affinity_propagate(x, guided, sparse_depth=None, prop_time=24, plan=None, state_dtype=None):
     """Functional form of CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54)."""
     _require_device(x, guided, sparse_depth)
+    if not (torch.is_grad_enabled() and (x.requires_grad or guided.requires_grad)):
+        return PACFunction.forward(_NoGradCtx, x, guided, sparse_depth, int(prop_time), plan, state_dtype)
     return PACFunction.apply(x, guided, sparse_depth, int(prop_time), plan, state_dtype)
