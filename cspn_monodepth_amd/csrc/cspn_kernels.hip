@@ -66,6 +66,27 @@ __device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 __device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
 
+// ------------------------------------------------------------------------------------------------
+// Tap-volume layout (the [B, K*K-1, H, W] weight volume the propagation streams)
+//   f32: planar, tap plane j of image b at ((b*NT + j)*HW + p).
+//   f16: taps interleaved in PAIRS per 4-pixel quad — [B][NT/2][ceil(HW/4)][2][4] — so that one 16-byte load
+//        returns taps (2i, 2i+1) of a quad.  8-byte loads run at about half the per-byte rate of 16-byte loads
+//        on gfx950; with planar f16 planes the kernel was slower than its f32 twin.
+// p = y*W + x is the linear pixel index inside an image; every kernel goes through Taps<WT>.
+// ------------------------------------------------------------------------------------------------
+template <typename WT> struct Taps;
+template <> struct Taps<float> {
+    __host__ __device__ static size_t image_elems(int NT, size_t HW) { return (size_t)NT * HW; }
+    __device__ static size_t idx(int j, size_t p, size_t HW) { return (size_t)j * HW + p; }
+};
+template <> struct Taps<__half> {
+    __host__ __device__ static size_t hw4(size_t HW) { return (HW + 3) & ~(size_t)3; }
+    __host__ __device__ static size_t image_elems(int NT, size_t HW) { return (size_t)NT * hw4(HW); }
+    __device__ static size_t idx(int j, size_t p, size_t HW) {
+        return (size_t)(j >> 1) * 2 * hw4(HW) + ((p >> 2) << 3) + ((size_t)(j & 1) << 2) + (p & 3);
+    }
+};
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) v4f* lds_cv4f_ptr;   // LDS (addrspace 3) volatile b128
 
@@ -77,6 +98,33 @@ __device__ __forceinline__ float dpp_from_prev_lane(float v) {
 __device__ __forceinline__ float dpp_from_next_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
+
+// All NT taps of the quad starting at pixel p (p % 4 == 0) of one image's tap volume -> out[NT][4] (fp32).
+template <int NT>
+__device__ __forceinline__ void load_taps_quad(const float* img, size_t p, size_t HW, bool ok, float (&out)[NT][4]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float4 v = ok ? ld4(img + (size_t)j * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out[j][0] = v.x; out[j][1] = v.y; out[j][2] = v.z; out[j][3] = v.w;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void load_taps_quad(const __half* img, size_t p, size_t HW, bool ok, float (&out)[NT][4]) {
+    const size_t pair_stride = 2 * Taps<__half>::hw4(HW);
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) raw = *reinterpret_cast<const uint4*>(img + (size_t)jp * pair_stride + 2 * p);
+        const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+        const float2 c = __half22float2(*reinterpret_cast<const __half2*>(&raw.z));
+        const float2 d = __half22float2(*reinterpret_cast<const __half2*>(&raw.w));
+        out[2 * jp][0] = a.x; out[2 * jp][1] = a.y; out[2 * jp][2] = b.x; out[2 * jp][3] = b.y;
+        out[2 * jp + 1][0] = c.x; out[2 * jp + 1][1] = c.y; out[2 * jp + 1][2] = d.x; out[2 * jp + 1][3] = d.y;
+    }
+}
+// ... and the matching quad store (used by the K x K backward epilogue, whose output is NOT a tap volume but a
+// plain [B,NT,H,W] gradient, so only the f32/f16 element type matters there): see st4.
 
 // blockIdx -> logical tile id such that XCD x (= blockIdx % 8, observed dispatch order; speed only,
 // never correctness) processes one contiguous range of tiles.
@@ -132,7 +180,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     const size_t HW = (size_t)H * W;
     const size_t plane = (size_t)a.B * HW;
 
-    const WT* __restrict__ wg = static_cast<const WT*>(a.w) + (size_t)b * NT * HW;
+    const WT* __restrict__ wg = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(NT, HW);
     const DT* __restrict__ din = static_cast<const DT*>(a.d_in) + (size_t)b * HW;
     const DT* __restrict__ spg = BLEND ? static_cast<const DT*>(a.sparse) + (size_t)b * HW : nullptr;
 
@@ -165,11 +213,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         const size_t off = (size_t)(ok ? y : 0) * W + (ok ? xq : 0);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (WSRC == 0) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float4 v = ok ? ld4(wg + (size_t)j * HW + off) : z4;
-                wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
-            }
+            load_taps_quad<NT>(wg, off, HW, ok, wreg[i]);
         } else {
             // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j.  The aligned quad of
             // row y+dy gives three of the four shifted values, the fourth is the neighbouring lane's quad
@@ -410,7 +454,7 @@ __global__ void cspn_prop_scalar(const void* w_, const void* din_, void* dout_, 
                     dv = ld1(din + (size_t)b * HW + (size_t)yy * W + xx);
                     if (BLEND == CSPN_BLEND_PREMASK) dv *= 1.f - sgnf(ld1(sp + (size_t)b * HW + (size_t)yy * W + xx));
                 }
-                u = fmaf(ld1(w + ((size_t)b * NT + j) * HW + p), dv, u);
+                u = fmaf(ld1(w + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(j, p, HW)), dv, u);
                 ++j;
             }
         if (BLEND == CSPN_BLEND_SPARSE) {
@@ -451,7 +495,7 @@ __global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs,
             S = (k == 0) ? v : S + v;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st1(w8 + ((size_t)b * 8 + j) * HW + p, a[j] / S);
+        for (int j = 0; j < 8; ++j) st1(w8 + (size_t)b * Taps<WT>::image_elems(8, HW) + Taps<WT>::idx(j, p, HW), a[j] / S);
         if (s_out) s_out[i] = S;
     }
 }
@@ -474,7 +518,7 @@ __global__ void cspn_pac_prepare_kernel(const GT* __restrict__ g, int B, int H, 
 #pragma unroll
         for (int c = 0; c < NT; ++c) { v[c] = expf(v[c] - mx); den += v[c]; }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) st1(wk + ((size_t)b * NT + c) * HW + p, v[c] / den);
+        for (int c = 0; c < NT; ++c) st1(wk + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(c, p, HW), v[c] / den);
     }
 }
 
@@ -496,8 +540,8 @@ __global__ void cspn_transpose_kernel(const WT* __restrict__ w, WT* __restrict__
                 const int yy = y + dy, xx = x + dx;
                 float v = 0.f;
                 if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                    v = ld1(w + ((size_t)b * NT + (NT - 1 - j)) * HW + (size_t)yy * W + xx);
-                st1(wT + ((size_t)b * NT + j) * HW + p, v);
+                    v = ld1(w + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(NT - 1 - j, (size_t)yy * W + xx, HW));
+                st1(wT + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(j, p, HW), v);
                 ++j;
             }
     }
@@ -571,7 +615,8 @@ __global__ void cspn3_grad_guidance_kernel(const GT* __restrict__ g, long bs, lo
                 float dot = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    dot = fmaf(gw[((size_t)b * 8 + k) * HW + p], ld1(w8 + ((size_t)b * 8 + k) * HW + p), dot);
+                    dot = fmaf(gw[((size_t)b * 8 + k) * HW + p],
+                               ld1(w8 + (size_t)b * Taps<WT>::image_elems(8, HW) + Taps<WT>::idx(k, p, HW)), dot);
                 const float gA = (gw[((size_t)b * 8 + j) * HW + p] - dot) / S[(size_t)b * HW + p];
                 val = sgnf(ld1(g + (size_t)b * bs + (size_t)(7 - j) * cs + q)) * gA;
             }
@@ -594,7 +639,7 @@ __global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const flo
         float dot = 0.f;
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
-            sm[c] = ld1(wk + ((size_t)b * NT + c) * HW + p);
+            sm[c] = ld1(wk + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(c, p, HW));
             gv[c] = gw[((size_t)b * NT + c) * HW + p];
             dot = fmaf(sm[c], gv[c], dot);
         }
@@ -753,33 +798,32 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) st4(gw + (size_t)j * HW, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
     } else if constexpr (VARIANT == 2) {
-        const WT* wk = static_cast<const WT*>(a.w) + (size_t)b * NT * HW + (size_t)y * W + x;
-        WT* gg = static_cast<WT*>(a.gout) + (size_t)b * NT * HW + (size_t)y * W + x;
+        const WT* wk = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(NT, HW);
+        WT* gg = static_cast<WT*>(a.gout) + (size_t)b * NT * HW + (size_t)y * W + x;   // plain [B,NT,H,W] gradient
         float dot[4] = {0.f, 0.f, 0.f, 0.f};
         float sm[NT][4];
+        load_taps_quad<NT>(wk, (size_t)y * W + x, HW, true, sm);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const float4 v = ld4(wk + (size_t)j * HW);
-            sm[j][0] = v.x; sm[j][1] = v.y; sm[j][2] = v.z; sm[j][3] = v.w;
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dot[e] = fmaf(sm[j][e], acc[j][e], dot[e]);
-        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
             st4(gg + (size_t)j * HW, make_float4(sm[j][0] * (acc[j][0] - dot[0]), sm[j][1] * (acc[j][1] - dot[1]),
                                                  sm[j][2] * (acc[j][2] - dot[2]), sm[j][3] * (acc[j][3] - dot[3])));
     } else {
         static_assert(VARIANT != 1 || K == 3, "guidance epilogue is the 3x3 variant");
-        const WT* w8 = static_cast<const WT*>(a.w) + (size_t)b * 8 * HW + (size_t)y * W + x;
+        const WT* w8 = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(8, HW);
         const WT* g = static_cast<const WT*>(a.guidance) + (size_t)b * a.g_bs;
         WT* gg = static_cast<WT*>(a.gout) + (size_t)b * a.g_bs;
         float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            float w4[8][4];
+            load_taps_quad<8>(w8, (size_t)y * W + x, HW, true, w4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 v = ld4(w8 + (size_t)j * HW);
-            const float w4[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dot[e] = fmaf(acc[j][e], w4[e], dot[e]);
+                for (int e = 0; e < 4; ++e) dot[e] = fmaf(acc[j][e], w4[j][e], dot[e]);
         }
         const float4 Sv = ld4(a.S + off);
         const float S4[4] = {Sv.x, Sv.y, Sv.z, Sv.w};
@@ -949,7 +993,7 @@ void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan
     (void)B; (void)keep_history;
     const int R = K / 2;
     p->force_scalar = 0;
-    p->threads = (K == 3) ? 1024 : (K == 5 ? 512 : 256);
+    p->threads = (K == 3) ? 1024 : 256;
     p->quads_per_thread = 1;
     int S = (K == 3) ? 8 : (K == 5 ? 3 : 2);
     if (T < 1) T = 1;

@@ -98,7 +98,7 @@ def autotune_plan(w, d0, sparse, K, T, blend, keep_history=False, reps=3, verbos
     """Time candidate_plans() on the actual tensors (HIP events on the current stream) and cache the fastest.
 
     Opt-in (`plan="auto"`): costs a few tens of ms once per (shape, dtype, blend) key."""
-    B, NT, H, W = w.shape
+    B, H, W = d0.shape
     key = (int(K), B, H, W, int(T), w.dtype, d0.dtype, int(blend), bool(keep_history), w.device.index)
     if key in _TUNED:
         return _TUNED[key]
@@ -208,6 +208,15 @@ def _plane(t, B, H, W, name):
     return t.contiguous()
 
 
+def _weight_buffer(B, NT, H, W, dtype, device):
+    """Tap volume for the engine (include/cspn_hip.h "tap-volume layout"): fp32 is the planar [B,NT,H,W];
+    fp16 is opaque — tap pairs interleaved per 4-pixel quad, [B, NT/2, ceil(HW/4), 2, 4] — returned as a
+    [B, NT, ceil4(HW)] tensor.  Only the engine's own kernels read or write it."""
+    if dtype == torch.float16:
+        return torch.empty((B, NT, (H * W + 3) // 4 * 4), dtype=dtype, device=device)
+    return torch.empty((B, NT, H, W), dtype=dtype, device=device)
+
+
 # ------------------------------------------------------------------------------------------------ raw ops
 def cspn3_prepare(guidance, want_s=False, w_dtype=None):
     """|g| -> shift -> /S: the 8 normalised weight planes of the 3x3 variant (CSPN_new.py:29-70,:124-127).
@@ -219,7 +228,7 @@ def cspn3_prepare(guidance, want_s=False, w_dtype=None):
     B, C, H, W = guidance.shape
     g = guidance if guidance.is_contiguous() else guidance.contiguous()
     w_dtype = g.dtype if w_dtype is None else w_dtype
-    w8 = torch.empty((B, 8, H, W), dtype=w_dtype, device=dev)
+    w8 = _weight_buffer(B, 8, H, W, w_dtype, dev)
     S = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_s else None
     with _device_guard(dev):
         ok = _lib.lib().cspn3_prepare(_p(g), _dt(g), g.stride(0), g.stride(1), B, H, W, _p(w8), _dt(w8), _p(S),
@@ -241,7 +250,7 @@ def pac_prepare(guided, w_dtype=None):
     w_dtype = g.dtype if w_dtype is None else w_dtype
     if w_dtype != g.dtype:
         raise TypeError("pac_prepare: weight dtype must equal guided dtype")
-    wk = torch.empty((B, C, H, W), dtype=w_dtype, device=dev)
+    wk = _weight_buffer(B, C, H, W, w_dtype, dev)
     with _device_guard(dev):
         ok = _lib.lib().cspn_pac_prepare(_p(g), _dt(g), B, H, W, K, _p(wk), _dt(wk), _stream(dev))
     _lib.check(ok, "cspn_pac_prepare")
@@ -249,13 +258,17 @@ def pac_prepare(guided, w_dtype=None):
 
 
 def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
-    """T steps of d <- blend(sum_j w_j * d[.+off_j]).  w [B,K*K-1,H,W]; d0, sparse [B,H,W].
+    """T steps of d <- blend(sum_j w_j * d[.+off_j]).  w: tap volume from cspn3_prepare / pac_prepare /
+    transpose_weights (see _weight_buffer); d0, sparse [B,H,W].
 
     Returns (d_T [B,H,W], history [T,B,H,W] or None); with history, d_T is history[T-1] (a view)."""
     dev = _require_device(w, d0, sparse)
-    B, NT, H, W = w.shape
-    if NT != K * K - 1:
-        raise ValueError("weight volume has %d planes, expected %d" % (NT, K * K - 1))
+    B, H, W = d0.shape
+    NT = K * K - 1
+    hw = (H * W + 3) // 4 * 4 if w.dtype == torch.float16 else H * W
+    if w.shape[0] != B or w.shape[1] != NT or w.numel() != B * NT * hw:
+        raise ValueError("weight volume of shape %s does not match K=%d and depth %s" % (
+            tuple(w.shape), K, tuple(d0.shape)))
     if not (w.is_contiguous() and d0.is_contiguous() and (sparse is None or sparse.is_contiguous())):
         raise ValueError("propagate: tensors must be contiguous")
     if sparse is not None and sparse.dtype != d0.dtype:
@@ -344,9 +357,9 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
     return out, None
 
 
-def transpose_weights(w, K):
+def transpose_weights(w, K, H, W):
     dev = _require_device(w)
-    B, NT, H, W = w.shape
+    B = w.shape[0]
     wT = torch.empty_like(w)
     with _device_guard(dev):
         ok = _lib.lib().cspn_transpose_weights(_p(w), _p(wT), _dt(w), B, H, W, int(K), _stream(dev))
@@ -358,12 +371,12 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan):
     """G_T = dL/dout, G_t = stencil^T((1-m) G_{t+1}): the forward kernel on the transposed weights.
     Returns ghist [T+1,B,H,W] f32 in backward order (ghist[s] = G_{T-s})."""
     dev = w.device
-    B, NT, H, W = w.shape
+    B, H, W = grad_out.shape[0], grad_out.shape[-2], grad_out.shape[-1]
     ghist = torch.empty((T + 1, B, H, W), dtype=torch.float32, device=dev)
     ghist[0].copy_(grad_out.reshape(B, H, W))
     if T > 0:
         sp32 = None if sparse is None else sparse.float()
-        wT = transpose_weights(w, K)
+        wT = transpose_weights(w, K, H, W)
         with _device_guard(dev):
             ok = _lib.lib().cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
                                            CSPN_F32, B, H, W, int(K), T,
@@ -379,7 +392,8 @@ def _tail_vector_ok(W, *tensors):
 
 def _grad_weights(w, K, T, d0, dhist, sparse, ghist):
     """Unfused dL/dw + dL/dd0 (any shape / alignment)."""
-    B, NT, H, W = w.shape
+    B, H, W = d0.shape
+    NT = K * K - 1
     gw = torch.empty((B, NT, H, W), dtype=torch.float32, device=w.device)
     gd0 = torch.empty((B, H, W), dtype=torch.float32, device=w.device)
     with _device_guard(w.device):
@@ -471,8 +485,9 @@ class PACFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         wk, d0, sp, hist = ctx.saved_tensors
-        B, NT, H, W = wk.shape
+        B, H, W = d0.shape
         K, T = ctx.K, ctx.prop_time
+        NT = K * K - 1
         L = _lib.lib()
         ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan)
         gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)

@@ -19,7 +19,13 @@
  *     before the call, as `with torch.cuda.device(...)` does at encoding.py:168.
  *
  * Tensor layout: NCHW contiguous planes.  "taps" are the K*K-1 non-centre offsets (dy,dx) in
- * row-major order over [-K/2, K/2]^2; tap plane j of a weight volume multiplies depth[p + off_j].
+ * row-major order over [-K/2, K/2]^2; tap j of a weight volume multiplies depth[p + off_j].
+ *
+ * Tap-volume layout (the `w8` / `wk` / `wT` buffers; produced and consumed only by this library):
+ *   CSPN_F32: planar [B, NT, H, W], NT = K*K-1.
+ *   CSPN_F16: tap PAIRS interleaved per 4-pixel quad, [B, NT/2, ceil(H*W/4), 2, 4] halfs (B*NT*ceil4(H*W)
+ *             elements), so one 16-byte load yields taps (2i, 2i+1) of a quad: 8-byte loads stream at about
+ *             half the per-byte rate on gfx950.
  */
 #ifndef CSPN_HIP_H_
 #define CSPN_HIP_H_

@@ -112,3 +112,27 @@ def test_fused_tail_equals_unfused_path(sparse, c_oracle):
         torch.cuda.synchronize()
         assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
         assert torch.allclose(gx, gx_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_fp16_backward_runs_and_tracks_fp32(c_oracle):
+    """fp16 storage (pair-interleaved tap volume) through the whole backward: loose agreement with fp64 oracle."""
+    B, H, W, T = 2, 24, 36, 6
+    g, d, s = c_oracle.synthetic_inputs(51, B, H, W, 12, 40)
+    cot = c_oracle.hash_normal(52, 9, (B, 1, H, W))
+    g16, d16, s16 = (a.astype(np.float16) for a in (g, d, s))
+    wg, wd = c_oracle.cspn3_backward(g16.astype(np.float32), d16.astype(np.float32), s16.astype(np.float32), cot, T, np.float64)
+    gt, dt = dev(g16, True), dev(d16, True)
+    out = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dt, dev(s16))
+    out.backward(dev(cot.astype(np.float16)))
+    assert gt.grad.dtype == torch.float16 and dt.grad.dtype == torch.float16
+    assert close(gt.grad.float().cpu().numpy(), wg, 3e-2) and close(dt.grad.float().cpu().numpy(), wd, 1e-2)
+    # K x K, fp16 guided with fp32 state (the reference's promotion) and fp16 state
+    K = 5
+    gd = c_oracle.hash_normal(53, 1, (B, 24, H, W)).astype(np.float16)
+    x = c_oracle.hash_uniform(53, 2, (B, 1, H, W), 0.0, 10.0).astype(np.float16)
+    wx, wgd = orc.pac_backward(x.astype(np.float32), gd.astype(np.float32), None, cot, T, np.float64)
+    for state in ("reference", None):
+        xt, gdt = dev(x, True), dev(gd, True)
+        o = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=state)(xt, gdt)
+        o.backward(dev(cot.astype(np.float32 if state == "reference" else np.float16)))
+        assert close(xt.grad.float().cpu().numpy(), wx, 1e-2) and close(gdt.grad.float().cpu().numpy(), wgd, 3e-2)

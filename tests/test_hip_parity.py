@@ -252,3 +252,42 @@ def test_metrics_kernel_golden():
     p = np.abs(t + rng.normal(0, 0.1, t.size).astype(np.float32)) + 0.01
     got = ev.metric_sums(dev(p.astype(np.float32)), dev(t)).cpu().numpy()
     assert np.allclose(got, orc.metric_sums(p.astype(np.float32), t), rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ fp16 storage
+def _half_close(got, want, tol=4e-3):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.abs(got - want).max()) <= tol * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 52), (1, 7, 18), (1, 5, 9), (2, 33, 64)])
+@pytest.mark.parametrize("plan", [None, dict(steps_per_launch=1, tile_w=32, tile_h=32, quads_per_thread=1, threads=256),
+                                  dict(steps_per_launch=4, tile_w=24, tile_h=26, quads_per_thread=2, threads=256)],
+                         ids=["default", "s1", "s4nq2"])
+def test_cspn3_fp16_storage(shape, plan, c_oracle):
+    """fp16 tap volume (pair-interleaved layout, incl. the padded HW % 4 != 0 case and the scalar kernel for
+    W % 4 != 0) with fp16 depth state: against the fp32 oracle on the fp16-rounded inputs."""
+    B, H, W = shape
+    g, d, s = c_oracle.synthetic_inputs(23, B, H, W, 12, max(2, H * W // 40))
+    g16, d16, s16 = (a.astype(np.float16) for a in (g, d, s))
+    want = c_oracle.cspn3_forward(g16.astype(np.float32), d16.astype(np.float32), s16.astype(np.float32), 8)
+    with torch.no_grad():
+        out = pkg.CSPN_new.AffinityPropagate(8, 3, plan=plan)(dev(g16), dev(d16), dev(s16))
+    assert out.dtype == torch.float16
+    assert _half_close(out.float().cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("K,T", [(3, 10), (5, 12), (7, 4)])
+@pytest.mark.parametrize("state", ["reference", None])
+def test_pac_fp16_storage(K, T, state, c_oracle):
+    B, H, W = 2, 36, 44
+    gd = c_oracle.hash_normal(K, 1, (B, K * K - 1, H, W)).astype(np.float16)
+    x = c_oracle.hash_uniform(K, 2, (B, 1, H, W), 0.0, 10.0).astype(np.float16)
+    s = c_oracle.hash_sparse(K, 3, x.astype(np.float32), 0.05).astype(np.float16)
+    want = c_oracle.pac_forward(x.astype(np.float32), gd.astype(np.float32), s.astype(np.float32), T)
+    plans = [None, dict(steps_per_launch=2, tile_w=24, tile_h=14 if K == 7 else 20, quads_per_thread=1, threads=256)]
+    for plan in plans:
+        with torch.no_grad():
+            out = pkg.CSPN_ours.AffinityPropagate(T, plan=plan, state_dtype=state)(dev(x), dev(gd), sparse_depth=dev(s))
+        assert out.dtype == (torch.float32 if state == "reference" else torch.float16)
+        assert _half_close(out.float().cpu().numpy(), want, 6e-3)

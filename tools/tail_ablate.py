@@ -19,4 +19,4 @@ gg = torch.empty_like(g); gd0 = torch.empty_like(d0)
 print("cspn3_backward_tail (variant 1): %.1f us" % timed(lambda: L.cspn3_backward_tail(P(d0), P(hist), P(ghist), None, P(g), g.stride(0), g.stride(1), 12, P(w8), P(S), P(gg), P(gd0), 0, B, H, W, T, st), 20))
 for TT in (1, 4, 12):
     print("  tail with T=%d: %.1f us" % (TT, timed(lambda: L.cspn3_backward_tail(P(d0), P(hist), P(ghist), None, P(g), g.stride(0), g.stride(1), 12, P(w8), P(S), P(gg), P(gd0), 0, B, H, W, TT, st), 20)))
-print("transpose: %.1f us" % timed(lambda: F.transpose_weights(w8, 3), 20))
+print("transpose: %.1f us" % timed(lambda: F.transpose_weights(w8, 3, H, W), 20))
