@@ -20,6 +20,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "cspn_hip.h"
 
@@ -65,6 +66,32 @@ __device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v
 
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 __device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
+
+// The 10 masked terms of Result.evaluate (libs/metrics.py:49-83) for one pixel, added to f[0..9]:
+// {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), 1} over t > 0.
+// Algebraically equal forms that avoid cancellation and redundant divisions:
+//   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)|,
+//   max(o/t, t/o) < c  <=>  o < c t  and  (o > 0 ? t < c o : o < 0)      (t > 0; NaN -> false as torch.max)
+// Reciprocals and the logarithm use the hardware v_rcp_f32 / v_log_f32 (1 ulp): the terms are summed over
+// ~10^5..10^6 pixels and compared at 1e-5, and IEEE divisions + log10f made this reduction VALU-bound.
+__device__ __forceinline__ void metric_terms(float o, float t, float (&f)[10]) {
+    if (!(t > 0.f)) return;
+    const float ad = fabsf(o - t);
+    const float rt = __builtin_amdgcn_rcpf(t);
+    const float inv = ad * __builtin_amdgcn_rcpf(fabsf(o * t));
+    f[0] = fmaf(inv, inv, f[0]);
+    f[1] += inv;
+    f[2] = fmaf(ad, ad, f[2]);
+    f[3] += ad;
+    f[4] = fmaf(ad, rt, f[4]);
+    f[5] += fabsf(__builtin_amdgcn_logf(o * rt)) * 0.30102999566398120f;     // |log10(o/t)| = |log2(o/t)| log10(2)
+    const float c1 = 1.25f, c2 = 1.25f * 1.25f, c3 = 1.25f * 1.25f * 1.25f;
+    const bool pos = o > 0.f, neg = o < 0.f;
+    f[6] += (o < c1 * t && (pos ? t < c1 * o : neg)) ? 1.f : 0.f;
+    f[7] += (o < c2 * t && (pos ? t < c2 * o : neg)) ? 1.f : 0.f;
+    f[8] += (o < c3 * t && (pos ? t < c3 * o : neg)) ? 1.f : 0.f;
+    f[9] += 1.f;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Tap-volume layout (the [B, K*K-1, H, W] weight volume the propagation streams)
@@ -140,6 +167,9 @@ __device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
 struct PropArgs {
     const void* w;       // [B,NT,H,W] tap planes, or (WSRC=1) the guidance tensor itself
     long g_bs, g_cs;     // WSRC=1: guidance batch / channel strides in elements
+    const void* target;  // SCORE=1: ground-truth depth [B,H,W] (DT) scored against the final state
+    double* macc;        // SCORE=1: [nslots][10] metric accumulators (cspn_metrics_accumulate layout)
+    int nslots;
     const void* d_in;    // [B,H,W]
     void* d_out;         // [B,H,W] state after the last fused step (may be null when hist != null)
     void* hist;          // null, or plane s-1 (stride B*H*W) receives the state after fused step s
@@ -160,7 +190,9 @@ template <int K, int NQ> struct MinWaves { static constexpr int value = (K == 3 
 // raw guidance itself — |g| of the 8 shifted channels, their sum, the IEEE divisions (exactly the arithmetic of
 // cspn3_prepare_kernel, CSPN_new.py:29-70/:124-127) — so inference needs no prepare pass and never
 // materialises the 8 weight planes (saves 53 MB written + 53 MB re-read per forward at config 2).
-template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND, int WSRC>
+// SCORE = 1: the launch that produces the final state also accumulates the depth metrics of its interior pixels
+// against `target` (the reduction cspn_metrics_kernel would do in a separate pass over the output).
+template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND, int WSRC, int SCORE = 0>
 __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_fused(const PropArgs a) {
     static_assert(WSRC == 0 || K == 3, "on-the-fly weights exist for the 3x3 variant only");
     constexpr int R = K / 2;
@@ -327,6 +359,11 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     DT* __restrict__ dout = a.d_out ? static_cast<DT*>(a.d_out) + (size_t)b * HW : nullptr;
     DT* __restrict__ hist = a.hist ? static_cast<DT*>(a.hist) + (size_t)b * HW : nullptr;
 
+    float mf[10];
+    if (SCORE) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) mf[k] = 0.f;
+    }
     for (int s = 1; s <= a.S; ++s) {
         const bool last = (s == a.S);
         if (active) {
@@ -414,6 +451,16 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                         const float4 uv = make_float4(u[0], u[1], u[2], u[3]);
                         if (hist) st4(hist + (size_t)(s - 1) * plane + off, uv);
                         else if (last) st4(dout + off, uv);
+                        if (SCORE && last) {
+                            const float4 tg = ld4(static_cast<const DT*>(a.target) + (size_t)b * HW + off);
+                            const float t4[4] = {tg.x, tg.y, tg.z, tg.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float o = u[e];
+                                if (sizeof(DT) == 2) o = __half2float(__float2half_rn(o));   // score the stored value
+                                metric_terms(o, t4[e], mf);
+                            }
+                        }
                     }
                 }
             }
@@ -421,6 +468,23 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         if (!last) {
             __syncthreads();
             float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    if (SCORE) {
+        // fp32 wave reduction (<= 256 pixels per wave), fp64 across the waves, 10 atomics per workgroup
+        float* part = lds + (size_t)2 * a.dr * a.ls + (size_t)(BLEND == CSPN_BLEND_SPARSE ? 2 : (BLEND ? 1 : 0)) * a.wr * 4 * a.wq;
+        const int wave = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            float v = mf[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) part[wave * 10 + k] = v;
+        }
+        __syncthreads();
+        if (tid < 10) {
+            double v = 0.0;
+            for (int w = 0; w < NTHREADS / 64; ++w) v += (double)part[w * 10 + tid];
+            if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + tid, v);
         }
     }
 }
@@ -881,29 +945,10 @@ __global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict
                                                             size_t n, int vec_ok, double* __restrict__ acc,
                                                             int nslots) {
     // Per-thread partial sums stay in fp32 (a thread sees ~a dozen pixels); fp64 starts at the wave reduction.
-    // Algebraically equal forms that avoid cancellation and redundant divisions:
-    //   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)|,
-    //   max(o/t, t/o) < c  <=>  o < c t  and  (o > 0 ? t < c o : o < 0)      (t > 0; NaN -> false as torch.max)
     float f[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) f[k] = 0.f;
-    auto one = [&](float o, float t) {
-        if (!(t > 0.f)) return;
-        const float ad = fabsf(o - t);
-        const float inv = ad / fabsf(o * t);
-        f[0] = fmaf(inv, inv, f[0]);
-        f[1] += inv;
-        f[2] = fmaf(ad, ad, f[2]);
-        f[3] += ad;
-        f[4] += ad / t;
-        f[5] += fabsf(log10f(o / t));
-        const float c1 = 1.25f, c2 = 1.25f * 1.25f, c3 = 1.25f * 1.25f * 1.25f;
-        const bool pos = o > 0.f, neg = o < 0.f;
-        f[6] += (o < c1 * t && (pos ? t < c1 * o : neg)) ? 1.f : 0.f;
-        f[7] += (o < c2 * t && (pos ? t < c2 * o : neg)) ? 1.f : 0.f;
-        f[8] += (o < c3 * t && (pos ? t < c3 * o : neg)) ? 1.f : 0.f;
-        f[9] += 1.f;
-    };
+    auto one = [&](float o, float t) { metric_terms(o, t, f); };
     const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * blockDim.x;
     const size_t nq = vec_ok ? n / 4 : 0;
@@ -972,7 +1017,8 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
     a.ls = 4 * a.wq + 8;
     if ((long)a.wq * ceil_div(a.wr, nq) > threads) return false;
     const int blend_planes = blend == CSPN_BLEND_SPARSE ? 2 : (blend == CSPN_BLEND_PREMASK ? 1 : 0);
-    L->lds_bytes = ((size_t)2 * a.dr * a.ls + (size_t)blend_planes * a.wr * 4 * a.wq) * sizeof(float);
+    L->lds_bytes = ((size_t)2 * a.dr * a.ls + (size_t)blend_planes * a.wr * 4 * a.wq + 16 * 10 /* SCORE partials */) *
+                   sizeof(float);
     if (L->lds_bytes > 160 * 1024) return false;
     L->grid = B * a.tiles_x * a.tiles_y;
     L->threads = threads;
@@ -1039,11 +1085,11 @@ void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const csp
     if (p->tile_h > hmax) p->tile_h = hmax;
 }
 
-template <int K, int NQ, int NTHREADS, typename WT, typename DT, int WSRC>
+template <int K, int NQ, int NTHREADS, typename WT, typename DT, int WSRC, int SCORE = 0>
 int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 #define CSPN_LAUNCH(BL)                                                                               \
     do {                                                                                              \
-        auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL, WSRC>;                               \
+        auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL, WSRC, SCORE>;                        \
         if (L.lds_bytes > 64 * 1024)                                                                  \
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes)); \
@@ -1062,6 +1108,19 @@ int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 
 template <int K, typename WT, typename DT>
 int launch_fused(const Launch& L, int blend, int wsrc, hipStream_t st) {
+    if (L.a.macc) {   // scoring launch: the one-quad instances the built-in plans use
+        if (wsrc || blend == CSPN_BLEND_PREMASK) return fail("scoring is available for prepared weights, forward only");
+        if constexpr (K == 3 || K == 5) {
+            if constexpr (std::is_same<WT, DT>::value) {
+#define CSPN_CASE_S(NQV, NTV) \
+    if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT, 0, 1>(L, blend, st)
+                CSPN_CASE_S(1, 256); CSPN_CASE_S(1, 512);
+                if constexpr (K == 3) { CSPN_CASE_S(1, 1024); CSPN_CASE_S(2, 512); }
+#undef CSPN_CASE_S
+            }
+        }
+        return fail("no scoring kernel instance for K=%d quads_per_thread=%d threads=%d", K, L.nq, L.threads);
+    }
     if constexpr (K == 3) {
         if (wsrc) {      // on-the-fly weights: one- and two-quad instances only
 #define CSPN_CASE_G(NQV, NTV) \
@@ -1111,7 +1170,8 @@ int launch_scalar(const void* w, const void* din, void* dout, const void* sp, co
 template <int K, typename WT, typename DT>
 int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
                     int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st,
-                    int wsrc = 0, long g_bs = 0, long g_cs = 0) {
+                    int wsrc = 0, long g_bs = 0, long g_cs = 0, const void* target = nullptr, double* macc = nullptr,
+                    int nslots = 0) {
     const size_t plane_bytes = (size_t)B * H * W * sizeof(DT);
     if (T == 0) {
         if (out) HIP_OK(hipMemcpyAsync(out, d0, plane_bytes, hipMemcpyDeviceToDevice, st));
@@ -1142,17 +1202,23 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
             dst = (t + S >= T) ? out : static_cast<void*>(wk + (size_t)(launch_idx & 1) * plane_bytes);
         }
         if (vec) {
-            Launch L;
+            Launch L{};
             if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, blend, &L))
                 return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
                             p.quads_per_thread, p.threads);
             L.a.w = w; L.a.g_bs = g_bs; L.a.g_cs = g_cs; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
             L.a.d_out = history ? nullptr : dst;
             L.a.hist = hist_base;
+            const bool final_launch = (t + S >= T);
+            L.a.target = final_launch ? target : nullptr;
+            L.a.macc = final_launch ? macc : nullptr;
+            L.a.nslots = nslots;
             if (!launch_fused<K, WT, DT>(L, blend, wsrc, st)) return 0;
         } else {
             if (wsrc) return fail("from-guidance propagation needs W %% 4 == 0 and 16-byte aligned tensors; "
                                   "use cspn3_prepare + cspn_propagate");
+            if (macc) return fail("scored propagation needs W %% 4 == 0 and 16-byte aligned tensors; use "
+                                  "cspn_propagate + cspn_metrics_accumulate");
             if (!launch_scalar<K, WT, DT>(w, src, dst, sparse, d0, B, H, W, blend, st)) return 0;
         }
         src = dst;
@@ -1287,6 +1353,25 @@ int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* spars
         case 7: return propagate_k<7>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
         default: return fail("cspn_propagate: unsupported K=%d (3, 5, 7)", K);
     }
+}
+
+int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* work,
+                          int d_dtype, int B, int H, int W, int K, int T, int blend, const void* target, double* acc,
+                          int nslots, const cspn_plan* plan, cspn_stream_t stream) {
+    if (!w || !d0 || !out || !target || !acc || nslots < 1 || B <= 0 || H <= 0 || W <= 0 || T < 1)
+        return fail("cspn_propagate_scored: bad arguments");
+    if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn_propagate_scored: blend %d", blend);
+    if (blend != CSPN_BLEND_NONE && !sparse) return fail("cspn_propagate_scored: blend needs sparse");
+    if (!aligned16(target)) return fail("cspn_propagate_scored: target must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define SCORED(KV, WTT, DTT) \
+    return propagate_typed<KV, WTT, DTT>(w, d0, sparse, out, nullptr, work, B, H, W, T, blend, plan, st, 0, 0, 0, target, acc, nslots)
+    if (K == 3 && w_dtype == CSPN_F32 && d_dtype == CSPN_F32) SCORED(3, float, float);
+    if (K == 3 && w_dtype == CSPN_F16 && d_dtype == CSPN_F16) SCORED(3, __half, __half);
+    if (K == 5 && w_dtype == CSPN_F32 && d_dtype == CSPN_F32) SCORED(5, float, float);
+    if (K == 5 && w_dtype == CSPN_F16 && d_dtype == CSPN_F16) SCORED(5, __half, __half);
+#undef SCORED
+    return fail("cspn_propagate_scored: unsupported K=%d / dtypes w=%d d=%d", K, w_dtype, d_dtype);
 }
 
 int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, const void* d0,

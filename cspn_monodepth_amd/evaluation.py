@@ -17,7 +17,7 @@ from . import _lib
 
 METRIC_NAMES = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
 N_SUMS = 10   # {inv^2, inv, diff^2, diff, diff/t, |dlog10|, #<1.25, #<1.25^2, #<1.25^3, n}
-N_SLOTS = 32  # accumulator rows the kernel spreads its fp64 atomics over (added up by finalize / all-gather)
+N_SLOTS = 1024  # accumulator rows: >= workgroups per launch, so no two blocks contend on one fp64 atomic address
 
 
 def new_accumulator(device):

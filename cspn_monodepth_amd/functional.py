@@ -309,6 +309,52 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
     return out, None
 
 
+_SCORED_INSTANCES = {3: ((1, 256), (1, 512), (1, 1024), (2, 512)), 5: ((1, 256), (1, 512))}
+
+
+def scored_supported(w, d0, sparse, target, K, T, plan=None):
+    """Can cspn_propagate_scored take this problem (else: propagate + evaluation.metric_sums)?"""
+    B, H, W = d0.shape
+    if K not in _SCORED_INSTANCES or T < 1 or W % 4 or w.dtype != d0.dtype or target.dtype != d0.dtype:
+        return False
+    if any(t is not None and t.data_ptr() % 16 for t in (w, d0, sparse, target)):
+        return False
+    p = resolve_plan(K, B, H, W, T, False, plan)
+    return not p["force_scalar"] and (p["quads_per_thread"], p["threads"]) in _SCORED_INSTANCES[K]
+
+
+def propagate_scored(w, d0, sparse, K, T, blend, target, acc, plan=None):
+    """propagate() whose final launch also adds the depth metrics of d_T vs `target` [B,H,W] into `acc`
+    (evaluation.new_accumulator): the refined batch is not re-read by a separate metrics pass."""
+    dev = _require_device(w, d0, sparse, target)
+    B, H, W = d0.shape
+    if acc.dtype != torch.float64 or acc.dim() != 2 or acc.shape[1] != 10 or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous float64 [nslots, 10] tensor (evaluation.new_accumulator)")
+    if not (target.is_contiguous() and tuple(target.shape) == (B, H, W)):
+        raise ValueError("target must be a contiguous [B,H,W] tensor")
+    L = _lib.lib()
+    out = torch.empty((B, H, W), dtype=d0.dtype, device=dev)
+    nbytes = L.cspn_propagate_workspace_bytes(B, H, W, int(T), _dt(d0), 0)
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+    log = _EVENT_LOG
+    with _device_guard(dev):
+        if log is not None:
+            ev0, ev1 = log.pair()
+            ev0.record(torch.cuda.current_stream(dev))
+        ok = L.cspn_propagate_scored(_p(w), _dt(w), _p(d0), _p(sparse), _p(out), _p(work), _dt(d0), B, H, W, int(K),
+                                     int(T), int(blend), _p(target), _p(acc), int(acc.shape[0]), _plan_ptr(K, plan),
+                                     _stream(dev))
+        if log is not None:
+            ev1.record(torch.cuda.current_stream(dev))
+            key = (K, B, H, W, T, False, id(plan))
+            if key not in log.plan_cache:
+                log.plan_cache[key] = resolve_plan(K, B, H, W, T, False, plan)["steps_per_launch"]
+            S = log.plan_cache[key]
+            log.append((ev0, ev1, -(-int(T) // max(S, 1)), S))
+    _lib.check(ok, "cspn_propagate_scored")
+    return out
+
+
 def from_guidance_supported(guidance, d0, sparse):
     """The fused prepare+propagate entry needs whole, 16-byte aligned quads (W % 4 == 0)."""
     W = guidance.shape[-1]
@@ -506,6 +552,49 @@ class PACFunction(torch.autograd.Function):
             gg = None
         gx = gx0.to(ctx.x_dtype).unsqueeze(1) if ctx.needs_input_grad[0] else None
         return gx, gg, None, None, None, None
+
+
+def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop_time=24, plan=None):
+    """Inference forward of the 3x3 module + metrics of the result vs `target` accumulated into `acc`
+    (evaluation.new_accumulator) — the eval loop's `model(input)` + `Result.evaluate` for the CSPN stage
+    (libs/trainers/single_gpu_trainer.py:129-140) with the metrics fused into the last propagation launch."""
+    from . import evaluation
+    dev = _require_device(guidance, blur_depth, sparse_depth, target)
+    B, C, H, W = guidance.shape
+    d0 = _plane(blur_depth, B, H, W, "blur_depth")
+    sp = _plane(sparse_depth, B, H, W, "sparse_depth")
+    tg = _plane(target, B, H, W, "target")
+    blend = BLEND_SPARSE if sp is not None else BLEND_NONE
+    with torch.no_grad():
+        w8, _, _ = cspn3_prepare(guidance)
+        if scored_supported(w8, d0, sp, tg, 3, prop_time, plan):
+            out = propagate_scored(w8, d0, sp, 3, prop_time, blend, tg, acc, plan)
+        else:
+            out, _ = propagate(w8, d0, sp, 3, prop_time, blend, plan=plan)
+            evaluation.metric_sums(out, tg, out=acc)
+    del dev
+    return out.unsqueeze(1)
+
+
+def pac_refine_and_score(x, guided, sparse_depth, target, acc, prop_time=24, plan=None, state_dtype=None):
+    """K x K twin of cspn3_refine_and_score."""
+    from . import evaluation
+    _require_device(x, guided, sparse_depth, target)
+    B, C, H, W = guided.shape
+    with torch.no_grad():
+        wk, K = pac_prepare(guided)
+        sdt = x.dtype if state_dtype is None else state_dtype
+        d0 = _plane(x, B, H, W, "x").to(sdt)
+        sp = _plane(sparse_depth, B, H, W, "sparse_depth")
+        sp = None if sp is None else sp.to(sdt)
+        tg = _plane(target, B, H, W, "target").to(sdt)
+        blend = BLEND_SPARSE if sp is not None else BLEND_NONE
+        if scored_supported(wk, d0, sp, tg, K, prop_time, plan):
+            out = propagate_scored(wk, d0, sp, K, prop_time, blend, tg, acc, plan)
+        else:
+            out, _ = propagate(wk, d0, sp, K, prop_time, blend, plan=plan)
+            evaluation.metric_sums(out, tg, out=acc)
+    return out.unsqueeze(1)
 
 
 def cspn3_affinity_propagate(guidance, blur_depth, sparse_depth=None, prop_time=24, plan=None):

@@ -8,7 +8,7 @@ The recurrence itself runs in libcspn_hip.so (hand-written gfx950 kernels); see 
 """
 import torch.nn as nn
 
-from ..functional import cspn3_affinity_propagate
+from ..functional import cspn3_affinity_propagate, cspn3_refine_and_score
 
 
 class AffinityPropagate(nn.Module):
@@ -31,3 +31,8 @@ class AffinityPropagate(nn.Module):
         """guidance [B,C>=8,H,W] (channels 0..7 used), blur_depth [B,1,H,W], sparse_depth [B,1,H,W] | None
         -> refined depth [B,1,H,W]."""
         return cspn3_affinity_propagate(guidance, blur_depth, sparse_depth, self.prop_time, self.plan)
+
+    def forward_scored(self, guidance, blur_depth, sparse_depth, target, acc):
+        """Extension (not in the reference): inference forward whose last propagation launch also accumulates the
+        depth metrics of the result vs `target` into `acc` (cspn_monodepth_amd.evaluation.new_accumulator)."""
+        return cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, self.prop_time, self.plan)

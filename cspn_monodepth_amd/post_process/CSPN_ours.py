@@ -8,7 +8,7 @@ K is inferred from the channel count (CSPN_ours.py:31-32).
 import torch
 import torch.nn as nn
 
-from ..functional import pac_affinity_propagate
+from ..functional import pac_affinity_propagate, pac_refine_and_score
 
 
 class AffinityPropagate(nn.Module):
@@ -28,3 +28,10 @@ class AffinityPropagate(nn.Module):
         if sdt == "reference":
             sdt = torch.float32 if x.dtype == torch.float16 else None
         return pac_affinity_propagate(x, guided, sparse_depth, self.times, self.plan, sdt)
+
+    def forward_scored(self, x, guided, sparse_depth, target, acc):
+        """Extension (not in the reference): see CSPN_new.AffinityPropagate.forward_scored."""
+        sdt = self.state_dtype
+        if sdt == "reference":
+            sdt = torch.float32 if x.dtype == torch.float16 else None
+        return pac_refine_and_score(x, guided, sparse_depth, target, acc, self.times, self.plan, sdt)

@@ -100,6 +100,15 @@ int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* spars
                    void* history, void* work, int d_dtype, int B, int H, int W, int K, int T,
                    int blend, const cspn_plan* plan, cspn_stream_t stream);
 
+/* cspn_propagate + cspn_metrics_accumulate in one: the launch that produces d_T also accumulates the depth
+ * metrics of its pixels against `target` [B,H,W] (d_dtype) into acc[nslots][10] (see cspn_metrics_accumulate),
+ * so the refined batch is not read back by a separate reduction pass.  Inference only (no history), prepared
+ * tap volume, K in {3,5}, w_dtype == d_dtype, W % 4 == 0 and 16-byte aligned tensors, a plan with one quad per
+ * thread (the built-in plans); returns 0 otherwise and the caller uses the two-call form. */
+int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* work,
+                          int d_dtype, int B, int H, int W, int K, int T, int blend, const void* target,
+                          double* acc, int nslots, const cspn_plan* plan, cspn_stream_t stream);
+
 /* 3x3 variant, inference: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
  * weights from the raw guidance (same arithmetic, bit-identical results), so the 8 weight planes are never
  * written to or re-read from HBM.  Arguments as cspn3_prepare (guidance, strides) + cspn_propagate.

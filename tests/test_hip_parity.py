@@ -291,3 +291,35 @@ def test_pac_fp16_storage(K, T, state, c_oracle):
             out = pkg.CSPN_ours.AffinityPropagate(T, plan=plan, state_dtype=state)(dev(x), dev(gd), sparse_depth=dev(s))
         assert out.dtype == (torch.float32 if state == "reference" else torch.float16)
         assert _half_close(out.float().cpu().numpy(), want, 6e-3)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_scored_forward_equals_forward_plus_metrics(sparse, c_oracle):
+    """forward_scored (metrics fused into the last propagation launch) = forward + evaluation.metric_sums."""
+    ev = pkg.evaluation
+    for (B, H, W, T, plan) in ((3, 100, 148, 24, None), (2, 37, 8, 7, None), (1, 9, 18, 5, None),   # last: W%4 != 0
+                               (2, 60, 64, 9, dict(steps_per_launch=3, tile_w=32, tile_h=28, quads_per_thread=2, threads=256))):
+        g, d, s = c_oracle.synthetic_inputs(29, B, H, W, 12, max(2, H * W // 50))
+        tgt = np.maximum(d + 0.1 * c_oracle.hash_normal(30, 9, d.shape), 0.0).astype(np.float32)
+        m = pkg.CSPN_new.AffinityPropagate(T, 3, plan=plan)
+        sp = dev(s) if sparse else None
+        with torch.no_grad():
+            ref = m(dev(g), dev(d), sp)
+            want = ev.metric_sums(ref, dev(tgt))
+            acc = ev.new_accumulator(DEV)
+            out = m.forward_scored(dev(g), dev(d), sp, dev(tgt), acc)
+        assert torch.equal(out, ref)
+        assert np.allclose(acc.sum(0).cpu().numpy(), want.cpu().numpy(), rtol=1e-5)
+    # K x K, fp32 and fp16 storage
+    K, T, B, H, W = 5, 6, 2, 40, 48
+    gd = c_oracle.hash_normal(31, 1, (B, 24, H, W)); x = c_oracle.hash_uniform(31, 2, (B, 1, H, W), 0.0, 10.0)
+    tgt = np.maximum(x + 0.1 * c_oracle.hash_normal(32, 9, x.shape), 0.0).astype(np.float32)
+    for dt in (np.float32, np.float16):
+        m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=None)
+        with torch.no_grad():
+            ref = m(dev(x.astype(dt)), dev(gd.astype(dt)))
+            want = ev.metric_sums(ref, dev(tgt.astype(dt)))
+            acc = ev.new_accumulator(DEV)
+            out = m.forward_scored(dev(x.astype(dt)), dev(gd.astype(dt)), None, dev(tgt.astype(dt)), acc)
+        assert torch.equal(out, ref)
+        assert np.allclose(acc.sum(0).cpu().numpy(), want.cpu().numpy(), rtol=1e-4 if dt == np.float16 else 1e-5)
