@@ -323,3 +323,65 @@ def test_scored_forward_equals_forward_plus_metrics(sparse, c_oracle):
             out = m.forward_scored(dev(x.astype(dt)), dev(gd.astype(dt)), None, dev(tgt.astype(dt)), acc)
         assert torch.equal(out, ref)
         assert np.allclose(acc.sum(0).cpu().numpy(), want.cpu().numpy(), rtol=1e-4 if dt == np.float16 else 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ runtime behaviour
+def test_thread_safety_and_streams(c_oracle):
+    """Re-entrancy: concurrent calls from several host threads, each on its own HIP stream
+    (the reference's DataParallel pattern, network/libs/base/encoding.py:160-186), give the serial results."""
+    import threading
+    B, H, W, T = 2, 60, 76, 12
+    cases = []
+    for i in range(4):
+        g, d, s = c_oracle.synthetic_inputs(60 + i, B, H, W, 12, 60)
+        cases.append((dev(g), dev(d), dev(s)))
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad():
+        serial = [m(*c).clone() for c in cases]
+    torch.cuda.synchronize()
+    results, errors = [None] * len(cases), []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(20):
+                    out = m(*cases[i])
+                st.synchronize()
+            results[i] = out
+        except Exception as e:       # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors
+    for a, b in zip(serial, results):
+        assert torch.equal(a, b)
+
+
+def test_hip_graph_capture_and_replay(c_oracle):
+    """The engine only enqueues kernels on the caller's stream (no allocation, no sync inside the .so), so a whole
+    forward can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed."""
+    B, H, W, T = 3, 228, 304, 24
+    g, d, s = c_oracle.synthetic_inputs(70, B, H, W, 12, 500)
+    gt, dt, st = dev(g), dev(d), dev(s)
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad():
+        ref = m(gt, dt, st).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                m(gt, dt, st)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(gt, dt, st)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        dt.mul_(0.5)                       # new input in the captured buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(out, 0.5 * ref, rtol=1e-5, atol=1e-6)
