@@ -70,7 +70,8 @@ def _declare(lib):
                                    ctypes.POINTER(cspn_plan), vp]
     lib.cspn_propagate_scored.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci,
                                           ctypes.POINTER(cspn_plan), vp]
-    lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci,
+    lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci,
+                                                  vp, vp, ci,
                                                   ctypes.POINTER(cspn_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]

@@ -67,6 +67,33 @@ __device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 __device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
 
+// q[k] = a[k] / S (k < 8, 0 <= a[k] <= S), bit-identical to IEEE division: this IS the arithmetic of the compiler's
+// fp32 division (v_div_scale, v_rcp, one Newton step on the reciprocal, q = a r, two residual corrections,
+// v_div_fmas, v_div_fixup) with the part that depends only on the divisor shared by the eight quotients —
+// 4 + 8*5 VALU operations instead of 8 * ~14.  The scale / fixup stages only act on extreme exponents and on
+// inf / nan / 0 operands, so anything outside a comfortable normal range takes the plain division.
+__device__ __forceinline__ void div8_shared_reciprocal(const float (&a)[8], float S, float (&q)[8]) {
+    bool fast = (S >= 0x1p-60f) && (S <= 0x1p+60f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fast = fast && (a[k] == 0.f || a[k] >= S * 0x1p-40f);
+    if (fast) {
+        float r = __builtin_amdgcn_rcpf(S);
+        const float e = fmaf(-S, r, 1.0f);
+        r = fmaf(e, r, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float qq = a[k] * r;
+            const float e2 = fmaf(-S, qq, a[k]);
+            qq = fmaf(e2, r, qq);
+            const float e3 = fmaf(-S, qq, a[k]);
+            q[k] = fmaf(e3, r, qq);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = a[k] / S;
+    }
+}
+
 // The 10 masked terms of Result.evaluate (libs/metrics.py:49-83) for one pixel, added to f[0..9]:
 // {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), 1} over t > 0.
 // Algebraically equal forms that avoid cancellation and redundant divisions:
@@ -150,8 +177,25 @@ __device__ __forceinline__ void load_taps_quad(const __half* img, size_t p, size
         out[2 * jp + 1][0] = c.x; out[2 * jp + 1][1] = c.y; out[2 * jp + 1][2] = d.x; out[2 * jp + 1][3] = d.y;
     }
 }
-// ... and the matching quad store (used by the K x K backward epilogue, whose output is NOT a tap volume but a
-// plain [B,NT,H,W] gradient, so only the f32/f16 element type matters there): see st4.
+// the matching quad stores
+template <int NT>
+__device__ __forceinline__ void store_taps_quad(float* img, size_t p, size_t HW, const float (&v)[NT][4]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) st4(img + (size_t)j * HW + p, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
+}
+template <int NT>
+__device__ __forceinline__ void store_taps_quad(__half* img, size_t p, size_t HW, const float (&v)[NT][4]) {
+    const size_t pair_stride = 2 * Taps<__half>::hw4(HW);
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+        uint4 raw;
+        *reinterpret_cast<__half2*>(&raw.x) = __floats2half2_rn(v[2 * jp][0], v[2 * jp][1]);
+        *reinterpret_cast<__half2*>(&raw.y) = __floats2half2_rn(v[2 * jp][2], v[2 * jp][3]);
+        *reinterpret_cast<__half2*>(&raw.z) = __floats2half2_rn(v[2 * jp + 1][0], v[2 * jp + 1][1]);
+        *reinterpret_cast<__half2*>(&raw.w) = __floats2half2_rn(v[2 * jp + 1][2], v[2 * jp + 1][3]);
+        *reinterpret_cast<uint4*>(img + (size_t)jp * pair_stride + 2 * p) = raw;
+    }
+}
 
 // blockIdx -> logical tile id such that XCD x (= blockIdx % 8, observed dispatch order; speed only,
 // never correctness) processes one contiguous range of tiles.
@@ -167,6 +211,7 @@ __device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
 struct PropArgs {
     const void* w;       // [B,NT,H,W] tap planes, or (WSRC=1) the guidance tensor itself
     long g_bs, g_cs;     // WSRC=1: guidance batch / channel strides in elements
+    void* w_out;         // WSRC=1: optional tap volume receiving the derived weights of the interior quads
     const void* target;  // SCORE=1: ground-truth depth [B,H,W] (DT) scored against the final state
     double* macc;        // SCORE=1: [nslots][10] metric accumulators (cspn_metrics_accumulate layout)
     int nslots;
@@ -305,8 +350,18 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                 float S = wreg[i][7][e];
 #pragma unroll
                 for (int k = 1; k < 8; ++k) S += wreg[i][7 - k][e];
+                float av[8], qv[8];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) wreg[i][j][e] = ok ? wreg[i][j][e] / S : 0.f;
+                for (int j = 0; j < 8; ++j) av[j] = wreg[i][j][e];
+                div8_shared_reciprocal(av, S, qv);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wreg[i][j][e] = ok ? qv[j] : 0.f;
+            }
+            // the launch that derives the weights can also publish them (tap-volume layout) for the launches
+            // that follow, which then stream them like a prepared volume
+            if (a.w_out && ((interior >> i) & 1u)) {
+                WT* wo = static_cast<WT*>(a.w_out) + (size_t)b * Taps<WT>::image_elems(NT, HW);
+                store_taps_quad<NT>(wo, off, HW, wreg[i]);
             }
         }
         if (BLEND && r < wr) {
@@ -558,8 +613,10 @@ __global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs,
             a[j] = v;
             S = (k == 0) ? v : S + v;
         }
+        float qv[8];
+        div8_shared_reciprocal(a, S, qv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st1(w8 + (size_t)b * Taps<WT>::image_elems(8, HW) + Taps<WT>::idx(j, p, HW), a[j] / S);
+        for (int j = 0; j < 8; ++j) st1(w8 + (size_t)b * Taps<WT>::image_elems(8, HW) + Taps<WT>::idx(j, p, HW), qv[j]);
         if (s_out) s_out[i] = S;
     }
 }
@@ -1109,7 +1166,8 @@ int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 template <int K, typename WT, typename DT>
 int launch_fused(const Launch& L, int blend, int wsrc, hipStream_t st) {
     if (L.a.macc) {   // scoring launch: the one-quad instances the built-in plans use
-        if (wsrc || blend == CSPN_BLEND_PREMASK) return fail("scoring is available for prepared weights, forward only");
+        if (wsrc || blend == CSPN_BLEND_PREMASK)
+            return fail("scoring needs a launch that streams prepared (or published) weights, forward only");
         if constexpr (K == 3 || K == 5) {
             if constexpr (std::is_same<WT, DT>::value) {
 #define CSPN_CASE_S(NQV, NTV) \
@@ -1171,7 +1229,7 @@ template <int K, typename WT, typename DT>
 int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
                     int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st,
                     int wsrc = 0, long g_bs = 0, long g_cs = 0, const void* target = nullptr, double* macc = nullptr,
-                    int nslots = 0) {
+                    int nslots = 0, void* w_out = nullptr) {
     const size_t plane_bytes = (size_t)B * H * W * sizeof(DT);
     if (T == 0) {
         if (out) HIP_OK(hipMemcpyAsync(out, d0, plane_bytes, hipMemcpyDeviceToDevice, st));
@@ -1206,14 +1264,20 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
             if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, blend, &L))
                 return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
                             p.quads_per_thread, p.threads);
-            L.a.w = w; L.a.g_bs = g_bs; L.a.g_cs = g_cs; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
+            // from-guidance with a weight buffer: the first launch derives + publishes the weights, the rest stream them
+            const bool derive = wsrc && (launch_idx == 0 || !w_out);
+            L.a.w = (wsrc && !derive) ? w_out : w;
+            L.a.w_out = (derive && n_launch > 1) ? w_out : nullptr;
+            L.a.g_bs = g_bs; L.a.g_cs = g_cs; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
             L.a.d_out = history ? nullptr : dst;
             L.a.hist = hist_base;
             const bool final_launch = (t + S >= T);
+            if (final_launch && macc && derive)
+                return fail("scored from-guidance propagation needs more than one launch (T > steps_per_launch)");
             L.a.target = final_launch ? target : nullptr;
             L.a.macc = final_launch ? macc : nullptr;
             L.a.nslots = nslots;
-            if (!launch_fused<K, WT, DT>(L, blend, wsrc, st)) return 0;
+            if (!launch_fused<K, WT, DT>(L, blend, derive ? 1 : 0, st)) return 0;
         } else {
             if (wsrc) return fail("from-guidance propagation needs W %% 4 == 0 and 16-byte aligned tensors; "
                                   "use cspn3_prepare + cspn_propagate");
@@ -1374,20 +1438,25 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
     return fail("cspn_propagate_scored: unsupported K=%d / dtypes w=%d d=%d", K, w_dtype, d_dtype);
 }
 
-int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, const void* d0,
+int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, void* w8_out, const void* d0,
                                   const void* sparse, void* out, void* history, void* work, int d_dtype, int B, int H,
-                                  int W, int T, int blend, const cspn_plan* plan, cspn_stream_t stream) {
+                                  int W, int T, int blend, const void* target, double* acc, int nslots,
+                                  const cspn_plan* plan, cspn_stream_t stream) {
+    if ((target || acc) && (!target || !acc || nslots < 1 || !w8_out || history || !aligned16(target) || g_dtype != d_dtype))
+        return fail("cspn3_propagate_from_guidance: scoring needs target, acc, nslots >= 1, w8_out, no history, "
+                    "one dtype and a 16-byte aligned target");
     if (!guidance || !d0 || B <= 0 || H <= 0 || W <= 0 || T < 0) return fail("cspn3_propagate_from_guidance: bad arguments");
     if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn3_propagate_from_guidance: blend %d", blend);
     if (blend != CSPN_BLEND_NONE && !sparse) return fail("cspn3_propagate_from_guidance: blend needs sparse");
     if ((cs & 3) || (bs & 3)) return fail("cspn3_propagate_from_guidance: guidance strides must be multiples of 4 elements");
+    if (w8_out && !aligned16(w8_out)) return fail("cspn3_propagate_from_guidance: w8_out must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g_dtype == CSPN_F32 && d_dtype == CSPN_F32)
-        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs);
+        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out);
     if (g_dtype == CSPN_F16 && d_dtype == CSPN_F16)
-        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs);
+        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out);
     if (g_dtype == CSPN_F16 && d_dtype == CSPN_F32)
-        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs);
+        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out);
     return fail("cspn3_propagate_from_guidance: unsupported dtypes g=%d d=%d", g_dtype, d_dtype);
 }
 

@@ -53,12 +53,13 @@ def resolve_plan(K, B, H, W, T, keep_history=False, plan=None):
     return {name: int(getattr(out, name)) for name, _ in cspn_plan._fields_}
 
 
-_FROM_GUIDANCE = False   # see set_from_guidance
+_FROM_GUIDANCE = True    # see set_from_guidance
 
 
 def set_from_guidance(enabled):
-    """Route no-grad 3x3 forwards through cspn3_propagate_from_guidance (saves the [B,8,H,W] weight buffer:
-    53 MB at config 2; bit-identical results; ~10 % slower than prepare + propagate on MI355X)."""
+    """Route no-grad 3x3 forwards through cspn3_propagate_from_guidance: the first launch derives the weights
+    from the raw guidance and publishes them for the later launches, so there is no separate prepare pass
+    (bit-identical results; ~8 % faster per forward at config 2 on MI355X).  False = cspn3_prepare + propagate."""
     global _FROM_GUIDANCE
     _FROM_GUIDANCE = bool(enabled)
 
@@ -309,6 +310,7 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
     return out, None
 
 
+_FROM_GUIDANCE_INSTANCES = ((1, 256), (2, 256), (1, 512), (2, 512), (1, 1024), (2, 1024))
 _SCORED_INSTANCES = {3: ((1, 256), (1, 512), (1, 1024), (2, 512)), 5: ((1, 256), (1, 512))}
 
 
@@ -355,15 +357,27 @@ def propagate_scored(w, d0, sparse, K, T, blend, target, acc, plan=None):
     return out
 
 
-def from_guidance_supported(guidance, d0, sparse):
-    """The fused prepare+propagate entry needs whole, 16-byte aligned quads (W % 4 == 0)."""
+def from_guidance_supported(guidance, d0, sparse, plan=None):
+    """The fused prepare+propagate entry needs whole, 16-byte aligned quads (W % 4 == 0) and a vector plan."""
     W = guidance.shape[-1]
+    forced = plan if plan is not None else _DEFAULT_PLANS.get(3)
+    if forced is not None:      # explicit plan: must resolve to one of the from-guidance kernel instances
+        if isinstance(forced, str):
+            return False
+        B, _, H, _ = guidance.shape
+        try:
+            p = resolve_plan(3, B, H, W, 1, False, forced)
+        except RuntimeError:
+            return False
+        if p["force_scalar"] or (p["quads_per_thread"], p["threads"]) not in _FROM_GUIDANCE_INSTANCES:
+            return False
     tensors = [t for t in (guidance, d0, sparse) if t is not None]
     return (W % 4 == 0 and guidance.is_contiguous() and guidance.stride(0) % 4 == 0 and guidance.stride(1) % 4 == 0
             and all(t.data_ptr() % 16 == 0 for t in tensors))
 
 
-def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, plan=None):
+def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, plan=None, publish_weights=True,
+                            score=None):
     """3x3 variant without a prepare pass: every launch derives the normalised weights from `guidance`
     (cspn3_propagate_from_guidance).  Same results, bit for bit, as cspn3_prepare + propagate."""
     dev = _require_device(guidance, d0, sparse)
@@ -390,8 +404,11 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
         if log is not None:
             ev0, ev1 = log.pair()
             ev0.record(torch.cuda.current_stream(dev))
-        ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(d0), _p(sparse), _p(out),
+        w8 = _weight_buffer(B, 8, H, W, g.dtype, dev) if publish_weights else None
+        tg, acc = score if score is not None else (None, None)
+        ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(w8), _p(d0), _p(sparse), _p(out),
                                              _p(hist), _p(work), _dt(d0), B, H, W, T, int(blend),
+                                             _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                              _plan_ptr(3, plan), _stream(dev))
         if log is not None:
             ev1.record(torch.cuda.current_stream(dev))
@@ -467,9 +484,8 @@ class CSPN3Function(torch.autograd.Function):
             raise TypeError("guidance / blur_depth / sparse_depth must share one dtype")
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
-        if not need_grad and _FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp):
-            # opt-in (set_from_guidance): no prepare pass and no 8-plane weight buffer; measured slower on
-            # MI355X (the per-launch divisions over the halo region cost more than the prepare pass saves)
+        if not need_grad and _FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan):
+            # inference: no separate prepare pass (the first launch derives and publishes the weights)
             out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan)
             return out.unsqueeze(1)
         w8, S, g = cspn3_prepare(guidance, want_s=need_grad)
@@ -566,6 +582,13 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
     tg = _plane(target, B, H, W, "target")
     blend = BLEND_SPARSE if sp is not None else BLEND_NONE
     with torch.no_grad():
+        if (_FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan) and guidance.dtype == d0.dtype
+                and tg.dtype == d0.dtype and tg.data_ptr() % 16 == 0):
+            p = resolve_plan(3, B, H, W, prop_time, False, plan)
+            if (prop_time > p["steps_per_launch"] and not p["force_scalar"]
+                    and (p["quads_per_thread"], p["threads"]) in _SCORED_INSTANCES[3]):
+                out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, score=(tg, acc))
+                return out.unsqueeze(1)
         w8, _, _ = cspn3_prepare(guidance)
         if scored_supported(w8, d0, sp, tg, 3, prop_time, plan):
             out = propagate_scored(w8, d0, sp, 3, prop_time, blend, tg, acc, plan)

@@ -112,12 +112,18 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
 /* 3x3 variant, inference: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
  * weights from the raw guidance (same arithmetic, bit-identical results), so the 8 weight planes are never
  * written to or re-read from HBM.  Arguments as cspn3_prepare (guidance, strides) + cspn_propagate.
+ * w8_out_or_null: NULL = every launch re-derives the weights (no weight volume at all); a [B,8,H,W] tap volume of
+ * g_dtype = the FIRST launch derives the weights and also publishes them there, the following launches stream
+ * them (one prepare pass and one read of the volume saved).
+ * target/acc/nslots: optional scoring of d_T as in cspn_propagate_scored (needs w8_out, no history, more than
+ * one launch, g_dtype == d_dtype).
  * Needs W % 4 == 0 and 16-byte aligned tensors (returns 0 otherwise: use the two-call form).
  * blend: CSPN_BLEND_NONE or CSPN_BLEND_SPARSE.  Replaces all of CSPN_new.py:29-92 for a forward pass. */
 int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
-                                  const void* d0, const void* sparse, void* out, void* history, void* work,
-                                  int d_dtype, int B, int H, int W, int T, int blend, const cspn_plan* plan,
-                                  cspn_stream_t stream);
+                                  void* w8_out_or_null, const void* d0, const void* sparse, void* out, void* history, void* work,
+                                  int d_dtype, int B, int H, int W, int T, int blend,
+                                  const void* target_or_null, double* acc_or_null, int nslots,
+                                  const cspn_plan* plan, cspn_stream_t stream);
 
 /* ---- backward ---------------------------------------------------------------------------------- */
 

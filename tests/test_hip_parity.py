@@ -162,16 +162,19 @@ def test_from_guidance_equals_prepare_plus_propagate(plan, sparse, c_oracle):
         assert torch.equal(a, b) and torch.equal(hist[T - 1], a)
         want = c_oracle.cspn3_forward(g, d, s if sparse else None, T)[:, 0]
         assert rel_err(b.cpu().numpy(), want) <= REL_TOL
-    # module-level switch
+        with torch.no_grad():
+            c, _ = F.propagate_from_guidance(gt, dt, st, T, blend, plan=plan, publish_weights=False)
+        assert torch.equal(a, c)
+    # module-level switch (default: from guidance)
     g, d, s = c_oracle.synthetic_inputs(18, 2, 40, 52, 12, 50)
     m = pkg.CSPN_new.AffinityPropagate(9, 3, plan=plan)
     with torch.no_grad():
         ref = m(dev(g), dev(d), dev(s) if sparse else None)
-        F.set_from_guidance(True)
+        F.set_from_guidance(False)
         try:
             alt = m(dev(g), dev(d), dev(s) if sparse else None)
         finally:
-            F.set_from_guidance(False)
+            F.set_from_guidance(True)
     assert torch.equal(ref, alt)
 
 
@@ -385,3 +388,37 @@ def test_hip_graph_capture_and_replay(c_oracle):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.allclose(out, 0.5 * ref, rtol=1e-5, atol=1e-6)
+
+
+def test_prepare_division_is_ieee_exact():
+    """cspn3_prepare's shared-reciprocal division must equal IEEE fp32 division bit for bit, including the
+    extreme-exponent / zero / inf / nan operands that take its slow path."""
+    from cspn_monodepth_amd import functional as F
+    torch.manual_seed(3)
+    B, H, W = 2, 64, 96
+    g = torch.randn(B, 8, H, W, device=DEV)
+    specials = torch.tensor([0.0, 1e-30, 1e30, 1e-41, 3e38, 1e-20, 1e20, float("inf"), float("nan"), 2.0 ** -60, 2.0 ** 60],
+                            device=DEV)
+    idx = torch.randint(0, g.numel(), (4000,), device=DEV)
+    g.view(-1)[idx] = specials[torch.randint(0, len(specials), (4000,), device=DEV)]
+    g[0, :, 10:14, 10:14] = 0.0                                   # all-zero neighbourhoods -> 0/0
+    g[1, :, 30:34, 40:48] *= 1e-25                                # uniformly tiny neighbourhoods
+    w8, S, _ = F.cspn3_prepare(g, want_s=True)
+    offs = [(+1, +1), (+1, 0), (+1, -1), (0, +1), (0, -1), (-1, +1), (-1, 0), (-1, -1)]     # o_k of reference plane k
+    A = []
+    for k, (dy, dx) in enumerate(offs):
+        a = torch.zeros(B, H, W, device=DEV)
+        ys, yd = (slice(dy, H), slice(0, H - dy)) if dy > 0 else ((slice(0, H + dy), slice(-dy, H)) if dy < 0 else (slice(0, H), slice(0, H)))
+        xs, xd = (slice(dx, W), slice(0, W - dx)) if dx > 0 else ((slice(0, W + dx), slice(-dx, W)) if dx < 0 else (slice(0, W), slice(0, W)))
+        a[:, yd, xd] = g[:, k, ys, xs].abs()
+        A.append(a)
+    Sref = A[0].clone()
+    for k in range(1, 8):
+        Sref = Sref + A[k]
+    assert torch.equal(torch.nan_to_num(S, nan=-1.0), torch.nan_to_num(Sref, nan=-1.0))
+    for j in range(8):
+        ref = A[7 - j] / Sref                                      # tap j <-> reference channel 7-j
+        got = w8[:, j]
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), j
+        assert torch.equal(torch.nan_to_num(got, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32),
+                           torch.nan_to_num(ref, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32)), j
