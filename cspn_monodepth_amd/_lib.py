@@ -14,7 +14,9 @@ import threading
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
-SRC = os.path.join(_PKG, "csrc", "cspn_kernels.hip")
+CSRC = os.path.join(_PKG, "csrc")
+SOURCES = ("cspn_propagate.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip")   # one TU each
+HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
@@ -36,16 +38,36 @@ class cspn_plan(ctypes.Structure):
 
 
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU.  In-tree output (travels with gpurun snapshots)."""
-    deps = [SRC, os.path.join(INCLUDE, "cspn_hip.h")]
+    """hipcc cross-compiles for gfx950 without a GPU: the translation units are compiled in parallel to
+    csrc/_build/*.o and linked into the in-tree .so (which travels with gpurun snapshots)."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [os.path.join(CSRC, f) for f in SOURCES]
+    deps = srcs + list(HEADERS)
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # -fno-slp-vectorize: the SLP pass pairs the stencil FMAs into v_pk_fma_f32 and pays for it with
-           # ~50 v_mov per step to build operand pairs; scalar v_fma_f32 measured 4 % faster (profiles/).
-           "-fno-fast-math", "-fno-slp-vectorize"] + os.environ.get("CSPN_HIPCC_FLAGS", "").split() + [
-           "-I", INCLUDE, "-o", SO_PATH + ".tmp", SRC]
+    # -fno-slp-vectorize: the SLP pass pairs the stencil FMAs into v_pk_fma_f32 and pays for it with ~50 v_mov
+    # per step to build operand pairs; scalar v_fma_f32 measured 4 % faster (profiles/).  No fast-math: 0/0 = NaN.
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fno-slp-vectorize"] + \
+        os.environ.get("CSPN_HIPCC_FLAGS", "").split() + ["-I", INCLUDE]
+    bdir = os.path.join(CSRC, "_build")
+    os.makedirs(bdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+                and all(os.path.getmtime(obj) >= os.path.getmtime(h) for h in HEADERS)
+                and not os.environ.get("CSPN_HIPCC_FLAGS")):
+            return obj
+        cmd = [hipcc] + flags + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,473 @@
+// cspn_backward.hip — backward tails of the propagation loop (the reverse recurrence itself reuses
+// cspn_prop_fused on the transposed weights).  See DESIGN.md §4.2.
+#include "cspn_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// backward helpers
+// ------------------------------------------------------------------------------------------------
+// gw_j[p] = (1-m) sum_t G_{t+1}[p] d_t[p+off_j];  gd0[p] = G_0[p] + m sum_{t>=1} G_t[p]
+template <int K, typename DT>
+__global__ void cspn_grad_weights_kernel(const DT* __restrict__ d0, const DT* __restrict__ dhist,
+                                         const float* __restrict__ ghist, const DT* __restrict__ sparse,
+                                         float* __restrict__ gw, float* __restrict__ gd0,
+                                         int B, int H, int W, int T) {
+    constexpr int R = K / 2;
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i - (size_t)b * HW);
+        const int y = p / W, x = p - y * W;
+        float acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = 0.f;
+        float gsum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const DT* d = (t == 0) ? d0 : dhist + (size_t)(t - 1) * total;
+            const float G = ghist[(size_t)(T - 1 - t) * total + i];   // G_{t+1}
+            gsum += G;
+            int j = 0;
+#pragma unroll
+            for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+                for (int dx = -R; dx <= R; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const int yy = y + dy, xx = x + dx;
+                    float dv = 0.f;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) dv = ld1(d + (size_t)b * HW + (size_t)yy * W + xx);
+                    acc[j] = fmaf(G, dv, acc[j]);
+                    ++j;
+                }
+        }
+        const float m = sparse ? sgnf(ld1(sparse + i)) : 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) gw[((size_t)b * NT + j) * HW + p] = (1.f - m) * acc[j];
+        gd0[i] = ghist[(size_t)T * total + i] + m * gsum;        // G_0 + m sum_{t>=1} G_t
+    }
+}
+
+// dL/dg_{7-j}[q] = sign(g) * gA_j[q - off_j],  gA_j = (gw_j - sum_k gw_k w_k) / S
+template <typename GT, typename WT>
+__global__ void cspn3_grad_guidance_kernel(const GT* __restrict__ g, long bs, long cs, int C,
+                                           const WT* __restrict__ w8, const float* __restrict__ S,
+                                           const float* __restrict__ gw, GT* __restrict__ gg,
+                                           int B, int H, int W) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int q = (int)(i - (size_t)b * HW);
+        const int y = q / W, x = q - y * W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+            const int yy = y - dy, xx = x - dx;       // p = q - off_j
+            float val = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const size_t p = (size_t)yy * W + xx;
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    dot = fmaf(gw[((size_t)b * 8 + k) * HW + p],
+                               ld1(w8 + (size_t)b * Taps<WT>::image_elems(8, HW) + Taps<WT>::idx(k, p, HW)), dot);
+                const float gA = (gw[((size_t)b * 8 + j) * HW + p] - dot) / S[(size_t)b * HW + p];
+                val = sgnf(ld1(g + (size_t)b * bs + (size_t)(7 - j) * cs + q)) * gA;
+            }
+            st1(gg + (size_t)b * bs + (size_t)(7 - j) * cs + q, val);
+        }
+        for (int c = 8; c < C; ++c) st1(gg + (size_t)b * bs + (size_t)c * cs + q, 0.f);
+    }
+}
+
+template <int K, typename WT, typename GT>
+__global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const float* __restrict__ gw,
+                                            GT* __restrict__ gg, int B, int H, int W) {
+    constexpr int NT = K * K - 1;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const size_t p = i - (size_t)b * HW;
+        float sm[NT], gv[NT];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            sm[c] = ld1(wk + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(c, p, HW));
+            gv[c] = gw[((size_t)b * NT + c) * HW + p];
+            dot = fmaf(sm[c], gv[c], dot);
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) st1(gg + ((size_t)b * NT + c) * HW + p, sm[c] * (gv[c] - dot));
+    }
+}
+
+// Fused backward tail (vector path, W % 4 == 0).  One thread owns a 4-pixel quad p and, in ONE pass over the two
+// histories (8 B/px/step of HBM traffic), accumulates
+//     acc_j[p] = sum_t G_{t+1}[p] * d_t[p+off_j]        (dL/dw_j up to the (1-m) factor)
+//     gsum[p]  = sum_t G_{t+1}[p]
+// in registers: per step one aligned 16-byte load of G and one per window row of d, horizontal neighbours by DPP
+// wave shifts (strip-end lanes patch with scalar loads).  The epilogue then never writes dL/dw at all:
+//   VARIANT 1 (3x3):  gA_j = ((1-m) acc_j - dot) / S, dot = sum_k (1-m) acc_k w_k   (quotient rule of w = A/S)
+//                     dL/dg_{7-j}[p+off_j] = sign(g) * gA_j[p]   scattered from the source side; targets
+//                     without a source (image border) and channels >= 8 are zero-filled here as well.
+//   VARIANT 2 (KxK):  dL/dguided_c = sm_c ((1-m) acc_c - sum_k (1-m) acc_k sm_k)    (softmax backward)
+//   VARIANT 0:        dL/dw_j = (1-m) acc_j   (raw, for callers that want it)
+// and gd0 = G_0 + m * gsum for all variants.
+struct TailArgs {
+    const void* d0;       // [B,H,W]   DT
+    const void* dhist;    // [T,B,H,W] DT  (d_1..d_T)
+    const float* ghist;   // [T+1,B,H,W] backward order: ghist[s] = G_{T-s}
+    const void* sparse;   // [B,H,W] DT or null
+    const void* w;        // [B,NT,H,W] WT tap planes (variants 1, 2)
+    const float* S;       // [B,H,W] (variant 1)
+    const void* guidance; // variant 1: [B,C,H,W] WT through strides
+    void* gout;           // variant 0: gw f32 [B,NT,H,W]; 1: grad_guidance WT (guidance strides); 2: grad_guided WT
+    float* gd0;           // [B,H,W]
+    long g_bs, g_cs;
+    int B, H, W, T, C;
+};
+
+template <int K, typename DT, typename WT, int VARIANT>
+__global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
+    constexpr int R = K / 2;
+    constexpr int NT = K * K - 1;
+    constexpr int WIN = 4 + 2 * R;
+    const int H = a.H, W = a.W, T = a.T;
+    const int WQ = W >> 2;
+    const size_t HW = (size_t)H * W;
+    const size_t plane = (size_t)a.B * HW;
+    const size_t nquads = (size_t)a.B * H * WQ;
+    // XCD-contiguous block order: vertically adjacent rows (shared window rows) stay within one XCD's L2
+    const size_t q = (size_t)xcd_contiguous_id(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const bool live = q < nquads;
+    const size_t qq = live ? q : 0;
+    const int b = (int)(qq / ((size_t)H * WQ));
+    const int rem = (int)(qq - (size_t)b * H * WQ);
+    const int y = rem / WQ, qx = rem - y * WQ, x = qx * 4;
+    const int lane = threadIdx.x & 63;
+    const bool fix_left = (qx == 0) || (lane == 0);
+    const bool fix_right = (qx == WQ - 1) || (lane == 63);
+    const size_t off = (size_t)b * HW + (size_t)y * W + x;
+    const DT* d0 = static_cast<const DT*>(a.d0);
+    const DT* dh = static_cast<const DT*>(a.dhist);
+
+    float acc[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // Software-pipelined stream over the histories: the loads of UNR steps (G quad, 2R+1 row quads, and the
+    // strip-end lanes' scalar halo patches) are all issued before the first one is consumed; otherwise every
+    // step (and every patch load) is a serialised HBM/L2 round trip and the pass is latency-bound.
+    constexpr int UNR = (K == 3) ? 4 : (K == 5 ? 2 : 1);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = 0; t0 < T; t0 += UNR) {
+        float4 Gq[UNR], midq[UNR][2 * R + 1];
+        float lf[UNR][2 * R + 1][R], rf[UNR][2 * R + 1][R];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int t = t0 + u;
+            const bool tv = live && t < T;
+            const DT* d = (t == 0) ? d0 : dh + (size_t)(tv ? t - 1 : 0) * plane;
+            Gq[u] = tv ? ld4(a.ghist + (size_t)(T - 1 - t) * plane + off) : z4;
+#pragma unroll
+            for (int rr = 0; rr < 2 * R + 1; ++rr) {
+                const int row = y + rr - R;
+                const bool rok = tv && row >= 0 && row < H;
+                const DT* rp = d + (size_t)b * HW + (size_t)(rok ? row : 0) * W;
+                midq[u][rr] = rok ? ld4(rp + x) : z4;
+#pragma unroll
+                for (int c = 0; c < R; ++c) { lf[u][rr][c] = 0.f; rf[u][rr][c] = 0.f; }
+                if (fix_left) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const int xx = x + c - R;
+                        lf[u][rr][c] = (rok && xx >= 0) ? ld1(rp + xx) : 0.f;
+                    }
+                }
+                if (fix_right) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const int xx = x + 4 + c;
+                        rf[u][rr][c] = (rok && xx < W) ? ld1(rp + xx) : 0.f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float g4[4] = {Gq[u].x, Gq[u].y, Gq[u].z, Gq[u].w};
+            float win[2 * R + 1][WIN];
+#pragma unroll
+            for (int rr = 0; rr < 2 * R + 1; ++rr) {
+                const float m4[4] = {midq[u][rr].x, midq[u][rr].y, midq[u][rr].z, midq[u][rr].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const float l = dpp_from_prev_lane(m4[4 - R + c]);
+                    const float r = dpp_from_next_lane(m4[c]);
+                    win[rr][c] = fix_left ? lf[u][rr][c] : l;
+                    win[rr][R + 4 + c] = fix_right ? rf[u][rr][c] : r;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gsum[e] += g4[e];
+#pragma unroll
+            for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+                for (int dx = -R; dx <= R; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const int lin = (dy + R) * K + (dx + R);
+                    const int j = lin < (K * K) / 2 ? lin : lin - 1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(g4[e], win[dy + R][e + dx + R], acc[j][e]);
+                }
+        }
+    }
+    if (!live) return;
+
+    float om[4] = {1.f, 1.f, 1.f, 1.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.sparse) {
+        const float4 sp = sgn4(ld4(static_cast<const DT*>(a.sparse) + off));
+        mm[0] = sp.x; mm[1] = sp.y; mm[2] = sp.z; mm[3] = sp.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) om[e] = 1.f - mm[e];
+    }
+    {
+        const float4 G0 = ld4(a.ghist + (size_t)T * plane + off);
+        st4(a.gd0 + off, make_float4(G0.x + mm[0] * gsum[0], G0.y + mm[1] * gsum[1], G0.z + mm[2] * gsum[2],
+                                     G0.w + mm[3] * gsum[3]));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] *= om[e];
+
+    if constexpr (VARIANT == 0) {
+        float* gw = static_cast<float*>(a.gout) + (size_t)b * NT * HW + (size_t)y * W + x;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) st4(gw + (size_t)j * HW, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
+    } else if constexpr (VARIANT == 2) {
+        const WT* wk = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(NT, HW);
+        WT* gg = static_cast<WT*>(a.gout) + (size_t)b * NT * HW + (size_t)y * W + x;   // plain [B,NT,H,W] gradient
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        float sm[NT][4];
+        load_taps_quad<NT>(wk, (size_t)y * W + x, HW, true, sm);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot[e] = fmaf(sm[j][e], acc[j][e], dot[e]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            st4(gg + (size_t)j * HW, make_float4(sm[j][0] * (acc[j][0] - dot[0]), sm[j][1] * (acc[j][1] - dot[1]),
+                                                 sm[j][2] * (acc[j][2] - dot[2]), sm[j][3] * (acc[j][3] - dot[3])));
+    } else {
+        static_assert(VARIANT != 1 || K == 3, "guidance epilogue is the 3x3 variant");
+        const WT* w8 = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(8, HW);
+        const WT* g = static_cast<const WT*>(a.guidance) + (size_t)b * a.g_bs;
+        WT* gg = static_cast<WT*>(a.gout) + (size_t)b * a.g_bs;
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            float w4[8][4];
+            load_taps_quad<8>(w8, (size_t)y * W + x, HW, true, w4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot[e] = fmaf(acc[j][e], w4[j][e], dot[e]);
+        }
+        const float4 Sv = ld4(a.S + off);
+        const float S4[4] = {Sv.x, Sv.y, Sv.z, Sv.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+            const size_t cplane = (size_t)(7 - j) * a.g_cs;
+            const int ty = y + dy;
+            float gA[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gA[e] = (acc[j][e] - dot[e]) / S4[e];
+            // Scatter gA_j[p] to p + off_j as ALIGNED quads of the target row ty: the target quad [x, x+4) takes
+            // source columns [x-dx, x+4-dx), i.e. three own values and one from the neighbouring lane (DPP).
+            // Where that neighbour sits in another wave (lane 0 / 63 inside a row) the element is written by its
+            // owner with one scalar store and skipped here; where it does not exist (image border) it is 0.
+            const float from_prev = dpp_from_prev_lane(gA[3]);
+            const float from_next = dpp_from_next_lane(gA[0]);
+            if (ty >= 0 && ty < H) {
+                const size_t o = cplane + (size_t)ty * W + x;
+                const float4 gs = sgn4(ld4(g + o));
+                if (dx == 0) {
+                    st4(gg + o, make_float4(gs.x * gA[0], gs.y * gA[1], gs.z * gA[2], gs.w * gA[3]));
+                } else if (dx > 0) {
+                    const float v0 = (qx == 0) ? 0.f : from_prev;              // column 0 has no source
+                    if (lane == 0 && qx > 0) {                                   // left neighbour lives in another wave
+                        st1(gg + o + 1, gs.y * gA[0]); st1(gg + o + 2, gs.z * gA[1]); st1(gg + o + 3, gs.w * gA[2]);
+                    } else {
+                        st4(gg + o, make_float4(gs.x * v0, gs.y * gA[0], gs.z * gA[1], gs.w * gA[2]));
+                    }
+                    if (lane == 63 && qx < WQ - 1) st1(gg + o + 4, sgnf(ld1(g + o + 4)) * gA[3]);
+                } else {
+                    const float v3 = (qx == WQ - 1) ? 0.f : from_next;         // column W-1 has no source
+                    if (lane == 63 && qx < WQ - 1) {
+                        st1(gg + o, gs.x * gA[1]); st1(gg + o + 1, gs.y * gA[2]); st1(gg + o + 2, gs.z * gA[3]);
+                    } else {
+                        st4(gg + o, make_float4(gs.x * gA[1], gs.y * gA[2], gs.z * gA[3], gs.w * v3));
+                    }
+                    if (lane == 0 && qx > 0) st1(gg + o - 1, sgnf(ld1(g + o - 1)) * gA[0]);
+                }
+            }
+            // rows of this plane that no source row reaches: row 0 (dy=+1) / row H-1 (dy=-1)
+            if ((dy > 0 && y == 0) || (dy < 0 && y == H - 1))
+                st4(gg + cplane + (size_t)y * W + x, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        for (int c = 8; c < a.C; ++c) st4(gg + (size_t)c * a.g_cs + (size_t)y * W + x, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+template <int K, typename DT, typename WT>
+int launch_tail(const TailArgs& a, int variant, hipStream_t st) {
+    const size_t nquads = (size_t)a.B * a.H * (a.W / 4);
+    const int grid = (int)((nquads + 255) / 256);
+    if (variant == 0) hipLaunchKernelGGL((cspn_grad_tail<K, DT, WT, 0>), dim3(grid), dim3(256), 0, st, a);
+    else if (variant == 2) hipLaunchKernelGGL((cspn_grad_tail<K, DT, WT, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if constexpr (K == 3) hipLaunchKernelGGL((cspn_grad_tail<3, DT, WT, 1>), dim3(grid), dim3(256), 0, st, a);
+    else return fail("backward tail variant %d unsupported for K=%d", variant, K);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+template <int K>
+int launch_tail_typed(const TailArgs& a, int variant, int d_dtype, int w_dtype, hipStream_t st) {
+    if (d_dtype == CSPN_F32 && w_dtype == CSPN_F32) return launch_tail<K, float, float>(a, variant, st);
+    if (d_dtype == CSPN_F16 && w_dtype == CSPN_F16) return launch_tail<K, __half, __half>(a, variant, st);
+    if (d_dtype == CSPN_F32 && w_dtype == CSPN_F16) return launch_tail<K, float, __half>(a, variant, st);
+    return fail("backward tail: unsupported dtypes d=%d w=%d", d_dtype, w_dtype);
+}
+
+bool tail_vector_ok(const TailArgs& a) {
+    return (a.W % 4 == 0) && aligned16(a.d0) && (!a.dhist || aligned16(a.dhist)) && aligned16(a.ghist) &&
+           (!a.sparse || aligned16(a.sparse)) && (!a.w || aligned16(a.w)) && (!a.S || aligned16(a.S)) &&
+           (!a.guidance || aligned16(a.guidance)) && aligned16(a.gout) && aligned16(a.gd0) &&
+           (a.g_bs % 4 == 0) && (a.g_cs % 4 == 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cspn_grad_weights(const void* d0, const void* dhist, const float* ghist, const void* sparse, float* gw,
+                      float* gd0, int d_dtype, int B, int H, int W, int K, int T, cspn_stream_t stream) {
+    if (!d0 || !ghist || !gw || !gd0 || (T > 1 && !dhist)) return fail("cspn_grad_weights: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {   // vector path: the fused tail without an epilogue (dL/dw written as is)
+        TailArgs a{};
+        a.d0 = d0; a.dhist = dhist; a.ghist = ghist; a.sparse = sparse; a.gout = gw; a.gd0 = gd0;
+        a.B = B; a.H = H; a.W = W; a.T = T;
+        if (tail_vector_ok(a) && (K == 3 || K == 5 || K == 7)) {
+            switch (K) {
+                case 3: return launch_tail_typed<3>(a, 0, d_dtype, d_dtype, st);
+                case 5: return launch_tail_typed<5>(a, 0, d_dtype, d_dtype, st);
+                default: return launch_tail_typed<7>(a, 0, d_dtype, d_dtype, st);
+            }
+        }
+    }
+    const int grid = grid_for((size_t)B * H * W, 256);
+#define GWK(KV)                                                                                                \
+    if (K == KV) {                                                                                             \
+        if (d_dtype == CSPN_F32)                                                                               \
+            hipLaunchKernelGGL((cspn_grad_weights_kernel<KV, float>), dim3(grid), dim3(256), 0, st,            \
+                               static_cast<const float*>(d0), static_cast<const float*>(dhist), ghist,         \
+                               static_cast<const float*>(sparse), gw, gd0, B, H, W, T);                        \
+        else                                                                                                   \
+            hipLaunchKernelGGL((cspn_grad_weights_kernel<KV, __half>), dim3(grid), dim3(256), 0, st,           \
+                               static_cast<const __half*>(d0), static_cast<const __half*>(dhist), ghist,       \
+                               static_cast<const __half*>(sparse), gw, gd0, B, H, W, T);                       \
+        HIP_OK(hipGetLastError());                                                                             \
+        return 1;                                                                                              \
+    }
+    GWK(3) GWK(5) GWK(7)
+#undef GWK
+    return fail("cspn_grad_weights: unsupported K=%d", K);
+}
+
+int cspn3_grad_guidance(const void* guidance, int g_dtype, long bs, long cs, int C, const void* w8, int w_dtype,
+                        const float* s, const float* gw, void* grad_guidance, int B, int H, int W,
+                        cspn_stream_t stream) {
+    if (!guidance || !w8 || !s || !gw || !grad_guidance) return fail("cspn3_grad_guidance: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+    if (g_dtype == CSPN_F32 && w_dtype == CSPN_F32)
+        hipLaunchKernelGGL((cspn3_grad_guidance_kernel<float, float>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const float*>(guidance), bs, cs, C, static_cast<const float*>(w8), s, gw,
+                           static_cast<float*>(grad_guidance), B, H, W);
+    else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F16)
+        hipLaunchKernelGGL((cspn3_grad_guidance_kernel<__half, __half>), dim3(grid), dim3(256), 0, st,
+                           static_cast<const __half*>(guidance), bs, cs, C, static_cast<const __half*>(w8), s, gw,
+                           static_cast<__half*>(grad_guidance), B, H, W);
+    else
+        return fail("cspn3_grad_guidance: unsupported dtypes g=%d w=%d", g_dtype, w_dtype);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* grad_guided, int g_dtype, int B,
+                         int H, int W, int K, cspn_stream_t stream) {
+    if (!wk || !gw || !grad_guided) return fail("cspn_pac_grad_guided: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((size_t)B * H * W, 256);
+#define PG(KV)                                                                                                 \
+    if (K == KV) {                                                                                             \
+        if (w_dtype == CSPN_F32 && g_dtype == CSPN_F32)                                                        \
+            hipLaunchKernelGGL((cspn_pac_grad_guided_kernel<KV, float, float>), dim3(grid), dim3(256), 0, st,  \
+                               static_cast<const float*>(wk), gw, static_cast<float*>(grad_guided), B, H, W);  \
+        else if (w_dtype == CSPN_F16 && g_dtype == CSPN_F16)                                                   \
+            hipLaunchKernelGGL((cspn_pac_grad_guided_kernel<KV, __half, __half>), dim3(grid), dim3(256), 0, st,\
+                               static_cast<const __half*>(wk), gw, static_cast<__half*>(grad_guided), B, H, W);\
+        else                                                                                                   \
+            return fail("cspn_pac_grad_guided: unsupported dtypes");                                           \
+        HIP_OK(hipGetLastError());                                                                             \
+        return 1;                                                                                              \
+    }
+    PG(3) PG(5) PG(7)
+#undef PG
+    return fail("cspn_pac_grad_guided: unsupported K=%d", K);
+}
+
+int cspn3_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+                        const void* guidance, long bs, long cs, int C, const void* w8, const float* s,
+                        void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T, cspn_stream_t stream) {
+    if (!d0 || !ghist || !guidance || !w8 || !s || !grad_guidance || !gd0 || (T > 1 && !dhist))
+        return fail("cspn3_backward_tail: NULL pointer");
+    TailArgs a{};
+    a.d0 = d0; a.dhist = dhist; a.ghist = ghist; a.sparse = sparse; a.w = w8; a.S = s; a.guidance = guidance;
+    a.gout = grad_guidance; a.gd0 = gd0; a.g_bs = bs; a.g_cs = cs; a.B = B; a.H = H; a.W = W; a.T = T; a.C = C;
+    if (!tail_vector_ok(a)) return fail("cspn3_backward_tail needs W %% 4 == 0 and 16-byte aligned tensors; use "
+                                        "cspn_grad_weights + cspn3_grad_guidance");
+    return launch_tail_typed<3>(a, 1, dtype, dtype, static_cast<hipStream_t>(stream));
+}
+
+int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse, const void* wk,
+                           void* grad_guided, float* gd0, int d_dtype, int w_dtype, int B, int H, int W, int K, int T,
+                           cspn_stream_t stream) {
+    if (!d0 || !ghist || !wk || !grad_guided || !gd0 || (T > 1 && !dhist)) return fail("cspn_pac_backward_tail: NULL pointer");
+    TailArgs a{};
+    a.d0 = d0; a.dhist = dhist; a.ghist = ghist; a.sparse = sparse; a.w = wk; a.gout = grad_guided; a.gd0 = gd0;
+    a.B = B; a.H = H; a.W = W; a.T = T;
+    if (!tail_vector_ok(a)) return fail("cspn_pac_backward_tail needs W %% 4 == 0 and 16-byte aligned tensors; use "
+                                        "cspn_grad_weights + cspn_pac_grad_guided");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (K) {
+        case 3: return launch_tail_typed<3>(a, 2, d_dtype, w_dtype, st);
+        case 5: return launch_tail_typed<5>(a, 2, d_dtype, w_dtype, st);
+        case 7: return launch_tail_typed<7>(a, 2, d_dtype, w_dtype, st);
+        default: return fail("cspn_pac_backward_tail: unsupported K=%d", K);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+// cspn_common.hpp — shared device/host helpers of the CSPN HIP engine (included by every translation unit).
+// Everything here has internal linkage (anonymous namespace / inline) except the thread-local error channel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "cspn_hip.h"
+
+namespace cspn_detail {
+// thread-local message of the last failing entry point on this thread (defined in cspn_metrics.hip)
+int fail(const char* fmt, ...);
+const char* last_error();
+}  // namespace cspn_detail
+
+namespace {
+
+using cspn_detail::fail;
+
+#define HIP_OK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// element access helpers: everything is computed in fp32, storage is f32 or f16
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __half* p) {
+    const uint2 raw = *reinterpret_cast<const uint2*>(p);
+    const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+    const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__half* p, float4 v) {
+    uint2 raw;
+    *reinterpret_cast<__half2*>(&raw.x) = __floats2half2_rn(v.x, v.y);
+    *reinterpret_cast<__half2*>(&raw.y) = __floats2half2_rn(v.z, v.w);
+    *reinterpret_cast<uint2*>(p) = raw;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v); }
+
+__device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+__device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
+
+// q[k] = a[k] / S (k < 8, 0 <= a[k] <= S), bit-identical to IEEE division: this IS the arithmetic of the compiler's
+// fp32 division (v_div_scale, v_rcp, one Newton step on the reciprocal, q = a r, two residual corrections,
+// v_div_fmas, v_div_fixup) with the part that depends only on the divisor shared by the eight quotients —
+// 4 + 8*5 VALU operations instead of 8 * ~14.  The scale / fixup stages only act on extreme exponents and on
+// inf / nan / 0 operands, so anything outside a comfortable normal range takes the plain division.
+__device__ __forceinline__ void div8_shared_reciprocal(const float (&a)[8], float S, float (&q)[8]) {
+    bool fast = (S >= 0x1p-60f) && (S <= 0x1p+60f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fast = fast && (a[k] == 0.f || a[k] >= S * 0x1p-40f);
+    if (fast) {
+        float r = __builtin_amdgcn_rcpf(S);
+        const float e = fmaf(-S, r, 1.0f);
+        r = fmaf(e, r, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float qq = a[k] * r;
+            const float e2 = fmaf(-S, qq, a[k]);
+            qq = fmaf(e2, r, qq);
+            const float e3 = fmaf(-S, qq, a[k]);
+            q[k] = fmaf(e3, r, qq);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = a[k] / S;
+    }
+}
+
+// The 10 masked terms of Result.evaluate (libs/metrics.py:49-83) for one pixel, added to f[0..9]:
+// {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), 1} over t > 0.
+// Algebraically equal forms that avoid cancellation and redundant divisions:
+//   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)|,
+//   max(o/t, t/o) < c  <=>  o < c t  and  (o > 0 ? t < c o : o < 0)      (t > 0; NaN -> false as torch.max)
+// Reciprocals and the logarithm use the hardware v_rcp_f32 / v_log_f32 (1 ulp): the terms are summed over
+// ~10^5..10^6 pixels and compared at 1e-5, and IEEE divisions + log10f made this reduction VALU-bound.
+__device__ __forceinline__ void metric_terms(float o, float t, float (&f)[10]) {
+    if (!(t > 0.f)) return;
+    const float ad = fabsf(o - t);
+    const float rt = __builtin_amdgcn_rcpf(t);
+    const float inv = ad * __builtin_amdgcn_rcpf(fabsf(o * t));
+    f[0] = fmaf(inv, inv, f[0]);
+    f[1] += inv;
+    f[2] = fmaf(ad, ad, f[2]);
+    f[3] += ad;
+    f[4] = fmaf(ad, rt, f[4]);
+    f[5] += fabsf(__builtin_amdgcn_logf(o * rt)) * 0.30102999566398120f;     // |log10(o/t)| = |log2(o/t)| log10(2)
+    const float c1 = 1.25f, c2 = 1.25f * 1.25f, c3 = 1.25f * 1.25f * 1.25f;
+    const bool pos = o > 0.f, neg = o < 0.f;
+    f[6] += (o < c1 * t && (pos ? t < c1 * o : neg)) ? 1.f : 0.f;
+    f[7] += (o < c2 * t && (pos ? t < c2 * o : neg)) ? 1.f : 0.f;
+    f[8] += (o < c3 * t && (pos ? t < c3 * o : neg)) ? 1.f : 0.f;
+    f[9] += 1.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tap-volume layout (the [B, K*K-1, H, W] weight volume the propagation streams)
+//   f32: planar, tap plane j of image b at ((b*NT + j)*HW + p).
+//   f16: taps interleaved in PAIRS per 4-pixel quad — [B][NT/2][ceil(HW/4)][2][4] — so that one 16-byte load
+//        returns taps (2i, 2i+1) of a quad.  8-byte loads run at about half the per-byte rate of 16-byte loads
+//        on gfx950; with planar f16 planes the kernel was slower than its f32 twin.
+// p = y*W + x is the linear pixel index inside an image; every kernel goes through Taps<WT>.
+// ------------------------------------------------------------------------------------------------
+template <typename WT> struct Taps;
+template <> struct Taps<float> {
+    __host__ __device__ static size_t image_elems(int NT, size_t HW) { return (size_t)NT * HW; }
+    __device__ static size_t idx(int j, size_t p, size_t HW) { return (size_t)j * HW + p; }
+};
+template <> struct Taps<__half> {
+    __host__ __device__ static size_t hw4(size_t HW) { return (HW + 3) & ~(size_t)3; }
+    __host__ __device__ static size_t image_elems(int NT, size_t HW) { return (size_t)NT * hw4(HW); }
+    __device__ static size_t idx(int j, size_t p, size_t HW) {
+        return (size_t)(j >> 1) * 2 * hw4(HW) + ((p >> 2) << 3) + ((size_t)(j & 1) << 2) + (p & 3);
+    }
+};
+
+#ifndef CSPN_DPP_BOUND_CTRL
+#define CSPN_DPP_BOUND_CTRL true
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) v4f* lds_cv4f_ptr;   // LDS (addrspace 3) volatile b128
+
+// Wavefront-level halo exchange: value held by lane-1 / lane+1 (DPP wave shift, VALU only).  Lanes without
+// a source (0 / 63) or with an exec-masked source get 0 (bound_ctrl) and are patched from LDS by the caller.
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, CSPN_DPP_BOUND_CTRL));
+}
+__device__ __forceinline__ float dpp_from_next_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, CSPN_DPP_BOUND_CTRL));
+}
+
+// All NT taps of the quad starting at pixel p (p % 4 == 0) of one image's tap volume -> out[NT][4] (fp32).
+template <int NT>
+__device__ __forceinline__ void load_taps_quad(const float* img, size_t p, size_t HW, bool ok, float (&out)[NT][4]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float4 v = ok ? ld4(img + (size_t)j * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out[j][0] = v.x; out[j][1] = v.y; out[j][2] = v.z; out[j][3] = v.w;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void load_taps_quad(const __half* img, size_t p, size_t HW, bool ok, float (&out)[NT][4]) {
+    const size_t pair_stride = 2 * Taps<__half>::hw4(HW);
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) raw = *reinterpret_cast<const uint4*>(img + (size_t)jp * pair_stride + 2 * p);
+        const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+        const float2 c = __half22float2(*reinterpret_cast<const __half2*>(&raw.z));
+        const float2 d = __half22float2(*reinterpret_cast<const __half2*>(&raw.w));
+        out[2 * jp][0] = a.x; out[2 * jp][1] = a.y; out[2 * jp][2] = b.x; out[2 * jp][3] = b.y;
+        out[2 * jp + 1][0] = c.x; out[2 * jp + 1][1] = c.y; out[2 * jp + 1][2] = d.x; out[2 * jp + 1][3] = d.y;
+    }
+}
+// the matching quad stores
+template <int NT>
+__device__ __forceinline__ void store_taps_quad(float* img, size_t p, size_t HW, const float (&v)[NT][4]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) st4(img + (size_t)j * HW + p, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
+}
+template <int NT>
+__device__ __forceinline__ void store_taps_quad(__half* img, size_t p, size_t HW, const float (&v)[NT][4]) {
+    const size_t pair_stride = 2 * Taps<__half>::hw4(HW);
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+        uint4 raw;
+        *reinterpret_cast<__half2*>(&raw.x) = __floats2half2_rn(v[2 * jp][0], v[2 * jp][1]);
+        *reinterpret_cast<__half2*>(&raw.y) = __floats2half2_rn(v[2 * jp][2], v[2 * jp][3]);
+        *reinterpret_cast<__half2*>(&raw.z) = __floats2half2_rn(v[2 * jp + 1][0], v[2 * jp + 1][1]);
+        *reinterpret_cast<__half2*>(&raw.w) = __floats2half2_rn(v[2 * jp + 1][2], v[2 * jp + 1][3]);
+        *reinterpret_cast<uint4*>(img + (size_t)jp * pair_stride + 2 * p) = raw;
+    }
+}
+
+// blockIdx -> logical tile id such that XCD x (= blockIdx % 8, observed dispatch order; speed only,
+// never correctness) processes one contiguous range of tiles.
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int x = bid & 7, j = bid >> 3;
+    return x * q + (x < r ? x : r) + j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small host helpers
+// ------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up4(int a) { return (a + 3) & ~3; }
+inline size_t esize(int dt) { return dt == CSPN_F16 ? 2 : 4; }
+
+int grid_for(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+
+}  // namespace
