@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
     ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the forward+backward leg")
     ap.add_argument("--no-per-step-leg", action="store_true", help="skip the S=1 schedule leg (profiling runs)")
     ap.add_argument("--cold-sets", type=int, default=4,
                     help="extra leg: rotate over this many input sets (> 256 MiB in total); 0/1 disables it")
@@ -327,6 +328,32 @@ def main():
                 "input_sets": len(sets), "footprint_MB": foot / 1e6, "steps": nc}
         del sets
 
+    # ---- training-shaped use of the same module (config 5's CSPN share): forward with history + hand-written backward
+    train = None
+    if rank == 0 and not args.no_train_leg:
+        gt = g.detach().clone().requires_grad_(True)
+        dt_ = d.detach().clone().requires_grad_(True)
+        cot = torch.randn_like(d)
+
+        def fwd_bwd():
+            gt.grad = None
+            dt_.grad = None
+            out = module(gt, dt_, s) if K == 3 else module(dt_, gt, s)
+            out.backward(cot.to(out.dtype))
+
+        for _ in range(5):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        nt = max(10, args.steps // 8)
+        t0t = time.perf_counter()
+        for _ in range(nt):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0t) / nt
+        train = {"fwd_bwd_us": dtt * 1e6, "maps_per_s": B_local / dtt, "steps": nt,
+                 "note": "CSPN module only (forward keeping T depth planes + reverse sweep + fused backward tail)"}
+        del gt, dt_, cot
+
     maps_total = (wl["B"] if strong else wl["B"] * world) * args.steps
     if rank == 0:
         res = {
@@ -363,6 +390,8 @@ def main():
             res["roofline_per_step_schedule"] = per_step
         if cold is not None:
             res["cache_cold"] = cold
+        if train is not None:
+            res["training_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(wl)

@@ -13,7 +13,7 @@ timeout 300 python tools/tune.py --workload nyu --sparse --out $O/tune_nyu_spars
 timeout 300 python bench.py --steps 200 --warmup 20 > $O/bench_default.log 2>&1
 timeout 300 python bench.py --steps 200 --warmup 20 --plan auto --no-cpu-baseline > $O/bench_auto.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-train-leg > $O/prof_bench.log 2>&1
 cd $R
 tail -3 $O/pytest_gpu.log
 for wl in nyu kitti pac5 nyu_sparse; do echo "== $wl"; grep -E "prepare|best:|module forward" $O/tune_$wl.log; done
