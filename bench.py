@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
     ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the forward+backward leg")
     ap.add_argument("--no-per-step-leg", action="store_true", help="skip the S=1 schedule leg (profiling runs)")
     ap.add_argument("--cold-sets", type=int, default=4,
@@ -150,10 +151,16 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.backend == "nccl":
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, n_dev))
+    torch.cuda.set_device(local_rank % n_dev)           # (gloo dry runs may oversubscribe one GPU)
+    device = torch.device("cuda", local_rank % n_dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     wl = dict(WORKLOADS[args.workload])
     strong = args.workload == "kitti"
@@ -227,7 +234,7 @@ def main():
             print("debug: host loop %.2f ms, gather call %.2f ms, final fence %.2f ms" % (
                 (t_loop - t0) * 1e3, (t_gather - t_loop) * 1e3, (t1 - t_gather) * 1e3), file=sys.stderr)
         F.set_event_log(None)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())

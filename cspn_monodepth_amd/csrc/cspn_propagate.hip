@@ -491,6 +491,14 @@ void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const csp
     if (p->tile_h > hmax) p->tile_h = hmax;
 }
 
+// (quads_per_thread, threads) pairs that have a compiled cspn_prop_fused instance (keep in step with launch_fused)
+bool has_instance(int K, int nq, int threads) {
+    if (K == 3) return ((nq == 1 || nq == 2) && (threads == 256 || threads == 512 || threads == 1024)) ||
+                       (nq == 4 && (threads == 256 || threads == 512)) || (nq == 8 && threads == 256);
+    if (K == 5) return (threads == 256 && nq >= 1 && nq <= 3) || (threads == 512 && nq == 1);
+    return K == 7 && nq == 1 && threads == 256;
+}
+
 template <int K, int NQ, int NTHREADS, typename WT, typename DT, int WSRC, int SCORE = 0>
 int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 #define CSPN_LAUNCH(BL)                                                                               \
@@ -664,6 +672,9 @@ int cspn_plan_resolve(int K, int B, int H, int W, int T, int keep_history, const
     if (K != 3 && K != 5 && K != 7) return fail("cspn_plan_resolve: unsupported K=%d", K);
     resolve_plan(K, B, H, W, T, keep_history, plan_or_null, resolved);
     if (!resolved->force_scalar) {
+        if (!has_instance(K, resolved->quads_per_thread, resolved->threads))
+            return fail("no kernel instance for K=%d quads_per_thread=%d threads=%d", K, resolved->quads_per_thread,
+                        resolved->threads);
         Launch L;
         if (!make_geometry(K, B, H, W, resolved->steps_per_launch, resolved->tile_w, resolved->tile_h,
                            resolved->quads_per_thread, resolved->threads, CSPN_BLEND_SPARSE /* worst-case LDS */, &L))

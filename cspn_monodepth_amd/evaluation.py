@@ -78,7 +78,10 @@ def all_gather_metric_sums(sums, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return sums.clone(), sums.unsqueeze(0).clone()
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(sums) for _ in range(world)]
-    dist.all_gather(parts, sums.contiguous(), group=group)
-    stacked = torch.stack(parts, 0)
+    src = sums.contiguous()
+    if sums.is_cuda and dist.get_backend(group) == "gloo":
+        src = src.cpu()                                   # gloo dry runs: gather through host memory
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    stacked = torch.stack(parts, 0).to(sums.device)
     return stacked.sum(0), stacked
