@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
     ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size (experiments)")
+    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph and replay it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the forward+backward leg")
     ap.add_argument("--no-per-step-leg", action="store_true", help="skip the S=1 schedule leg (profiling runs)")
@@ -163,6 +165,9 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     wl = dict(WORKLOADS[args.workload])
+    if args.batch > 0:
+        wl["B"] = args.batch
+        wl["name"] += " [batch overridden to %d]" % args.batch
     strong = args.workload == "kitti"
     if strong:                                        # config 4: the batch of 8 is sharded across the ranks
         lo, hi = pkg.evaluation.shard_bounds(wl["B"], rank, world)
@@ -200,6 +205,14 @@ def main():
     def step():
         # the eval step of the pipeline: refine the batch and score it (metrics fused into the last launch)
         return run() if args.no_metrics else run_scored(sums)
+
+    if args.graph:
+        # replay the whole step as one HIP graph (inputs are already resident: no per-step copies)
+        eager_step = step
+        graphed = pkg.graphs.GraphedForward(lambda: eager_step())
+
+        def step():                                                # noqa: F811
+            return graphed(copy_inputs=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -381,7 +394,7 @@ def main():
             "config": {"workload": wl["name"], "batch_per_gpu": B_local, "H": wl["H"], "W": wl["W"], "K": K,
                        "prop_time": T, "guidance_channels": wl["C"], "sparse": bool(args.sparse),
                        "step": "prepare + %d propagation steps%s" % (T, "" if args.no_metrics else " + depth metrics (fused into the last launch)"),
-                       "plan": eff_plan, "parallelism": "batch-shard x%d, metrics all-gather" % world},
+                       "plan": eff_plan, "hip_graph": bool(args.graph), "parallelism": "batch-shard x%d, metrics all-gather" % world},
             "roofline": {"bound": "hbm", "kernel": "cspn_prop_fused", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,

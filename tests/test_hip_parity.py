@@ -422,3 +422,23 @@ def test_prepare_division_is_ieee_exact():
         assert torch.equal(torch.isnan(got), torch.isnan(ref)), j
         assert torch.equal(torch.nan_to_num(got, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32),
                            torch.nan_to_num(ref, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32)), j
+
+
+def test_graphed_forward_helper(c_oracle):
+    g, d, s = c_oracle.synthetic_inputs(71, 1, 64, 96, 12, 80)
+    tgt = np.maximum(d + 0.1 * c_oracle.hash_normal(72, 9, d.shape), 0.0).astype(np.float32)
+    m = pkg.CSPN_new.AffinityPropagate(24, 3)
+    acc = pkg.evaluation.new_accumulator(DEV)
+    gt, dt, st, tt = dev(g), dev(d), dev(s), dev(tgt)
+    with torch.no_grad():
+        ref = m(gt, dt, st).clone()
+        want = pkg.evaluation.metric_sums(ref, tt)
+    graphed = pkg.graphs.GraphedForward(lambda a, b, c, t: m.forward_scored(a, b, c, t, acc), gt, dt, st, tt)
+    acc.zero_()
+    out = graphed(gt, dt, st, tt)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert np.allclose(acc.sum(0).cpu().numpy(), want.cpu().numpy(), rtol=1e-5)
+    out2 = graphed(gt, dt * 0.5, st * 0.5, tt)         # fresh inputs are copied into the captured buffers
+    torch.cuda.synchronize()
+    assert torch.allclose(out2, 0.5 * ref, rtol=1e-5, atol=1e-6)
