@@ -374,6 +374,22 @@ def main():
                  "note": "CSPN module only (forward keeping T depth planes + reverse sweep + fused backward tail)"}
         del gt, dt_, cot
 
+    # ---- what a plain device copy achieves on this GPU (fraction of achievable, next to nominal)
+    copy_gbs = None
+    if rank == 0:
+        src_c = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=device)      # 256 MiB, beyond the L2
+        dst_c = torch.empty_like(src_c)
+        for _ in range(3):
+            dst_c.copy_(src_c)
+        e0c, e1c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0c.record()
+        for _ in range(10):
+            dst_c.copy_(src_c)
+        e1c.record()
+        e1c.synchronize()
+        copy_gbs = 10 * 2 * src_c.numel() * 4 / (e0c.elapsed_time(e1c) / 1e3) / 1e9
+        del src_c, dst_c
+
     maps_total = (wl["B"] if strong else wl["B"] * world) * args.steps
     if rank == 0:
         res = {
@@ -406,7 +422,12 @@ def main():
             "metrics_check": {k: v for k, v in pkg.evaluation.finalize_metrics(total.cpu()).items()
                               if k in ("rmse", "absrel", "delta1", "count")},
         }
+        if copy_gbs:
+            res["roofline"]["device_copy_GBs"] = copy_gbs
         if per_step is not None:
+            if copy_gbs:
+                per_step["device_copy_GBs"] = copy_gbs
+                per_step["frac_of_device_copy"] = per_step["achieved"] / copy_gbs
             res["roofline_per_step_schedule"] = per_step
         if cold is not None:
             res["cache_cold"] = cold
