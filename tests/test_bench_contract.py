@@ -1,0 +1,49 @@
+"""GPU test of the bench.py contract the driver depends on: one JSON line with the agreed keys, exactly K timed
+steps, roofline + cpu_baseline objects, and the same under a torch.distributed launch (world size 1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _run(cmd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_json_line():
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "12", "--warmup", "2", "--prewarm-s", "0.05"])
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "depth-maps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 24 * 12 / (d["ms_per_step"] * 12 / 1e3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["launches_timed"] == 12 * 3
+    p = d["roofline_per_step_schedule"]
+    assert p["plan"]["steps_per_launch"] == 1 and 0.5 < p["frac"] < 1.0       # the >= 50 % of HBM roofline target
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["cache_cold"]["footprint_MB"] > 256
+    assert d["metrics_check"]["count"] > 0
+
+
+def test_torchrun_world_size_one():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+              "127.0.0.1", "--master-port", "29577", "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "1",
+              "--prewarm-s", "0.05", "--no-cpu-baseline", "--no-train-leg", "--cold-sets", "0", "--workload", "kitti"])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 6 and d["scaling"] == "strong"

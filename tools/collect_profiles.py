@@ -22,10 +22,11 @@ if os.path.exists(ks):
         for r in rows:
             if "cspn" in r["Name"]:
                 f.write(",".join('"%s"' % r[k] if k == "Name" else r[k] for k in cols) + "\n")
-t = os.path.join(G, "pmc_out", "traffic_nyu.json")
-if os.path.exists(t):
-    shutil.copy(t, os.path.join(P, "traffic_nyu.json"))
-    shutil.copy(t, os.path.join(P, "%s_pmc_traffic_nyu.json" % tag))
+for w in ("nyu", "kitti", "pac5"):
+    t = os.path.join(G, "pmc_out", "traffic_%s.json" % w)
+    if os.path.exists(t):
+        shutil.copy(t, os.path.join(P, "traffic_%s.json" % w))
+        shutil.copy(t, os.path.join(P, "%s_pmc_traffic_%s.json" % (tag, w)))
 for w in ("nyu", "kitti", "pac5", "nyu_sparse"):
     f = os.path.join(G, "tune_%s.log" % w)
     if os.path.exists(f):

@@ -8,7 +8,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   tag=$(echo $ctr | tr ' ' '+')
-  for plan in default "1,32,29,1,256"; do
+  STEP_PLAN=${2:-"1,32,29,1,256"}
+  for plan in default "$STEP_PLAN"; do
     ptag=$( [ "$plan" = default ] && echo fused || echo step )
     extra=""; [ "$plan" = default ] || extra="--plan $plan"
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${WL}_${ptag}_$tag -o pmc -- \
