@@ -84,15 +84,15 @@ def _declare(lib):
     lib.cspn_abi_version.restype = ci
     lib.cspn_last_error.restype = ctypes.c_char_p
     lib.cspn_plan_resolve.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_plan), ctypes.POINTER(cspn_plan)]
-    lib.cspn3_prepare.argtypes = [vp, ci, cl, cl, ci, ci, ci, vp, ci, vp, vp]
+    lib.cspn3_prepare.argtypes = [vp, ci, cl, cl, ci, ci, ci, ci, vp, ci, vp, vp]
     lib.cspn_pac_prepare.argtypes = [vp, ci, ci, ci, ci, ci, vp, ci, vp]
     lib.cspn_propagate_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci]
     lib.cspn_propagate_workspace_bytes.restype = cs
-    lib.cspn_propagate.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
+    lib.cspn_propagate.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
                                    ctypes.POINTER(cspn_plan), vp]
-    lib.cspn_propagate_scored.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci,
+    lib.cspn_propagate_scored.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci,
                                           ctypes.POINTER(cspn_plan), vp]
-    lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci,
+    lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
                                                   vp, vp, ci,
                                                   ctypes.POINTER(cspn_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
@@ -120,7 +120,7 @@ def lib():
                         "cspn_monodepth_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % SO_PATH)
                 _lib = _declare(ctypes.CDLL(SO_PATH))
-                if _lib.cspn_abi_version() != 1:
+                if _lib.cspn_abi_version() != 2:
                     raise RuntimeError("cspn_monodepth_amd: ABI version mismatch")
     return _lib
 

@@ -10,7 +10,7 @@ namespace {
 // 3x3: w_j[p] = |g_{7-j}[p+off_j]| / S[p],  S[p] = sum_{k=0..7} |g_k[p+o_k]| summed in the
 // reference's channel order k = 0..7 (CSPN_new.py:29-70, :124-127).  True IEEE division.
 template <typename GT, typename WT>
-__global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs, int B, int H, int W,
+__global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs, int B, int H, int W, int Wv,
                                      WT* __restrict__ w8, float* __restrict__ s_out) {
     const size_t HW = (size_t)H * W;
     const size_t total = (size_t)B * HW;
@@ -35,6 +35,11 @@ __global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs,
         }
         float qv[8];
         div8_shared_reciprocal(a, S, qv);
+        if (x >= Wv) {               // row-padding column: no weights, and a divisor the backward can divide by
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv[j] = 0.f;
+            S = 1.f;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) st1(w8 + (size_t)b * Taps<WT>::image_elems(8, HW) + Taps<WT>::idx(j, p, HW), qv[j]);
         if (s_out) s_out[i] = S;
@@ -130,20 +135,22 @@ __global__ void cspn_transpose_kernel(const WT* __restrict__ w, WT* __restrict__
 
 extern "C" {
 
-int cspn3_prepare(const void* guidance, int g_dtype, long bs, long cs, int B, int H, int W, void* w8,
+int cspn3_prepare(const void* guidance, int g_dtype, long bs, long cs, int B, int H, int W, int W_valid, void* w8,
                   int w_dtype, float* s_or_null, cspn_stream_t stream) {
-    if (!guidance || !w8 || B <= 0 || H <= 0 || W <= 0) return fail("cspn3_prepare: bad arguments");
+    if (!guidance || !w8 || B <= 0 || H <= 0 || W <= 0 || W_valid < 0 || W_valid > W)
+        return fail("cspn3_prepare: bad arguments");
+    const int Wv = W_valid > 0 ? W_valid : W;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for((size_t)B * H * W, 256);
     if (g_dtype == CSPN_F32 && w_dtype == CSPN_F32)
         hipLaunchKernelGGL((cspn3_prepare_kernel<float, float>), dim3(grid), dim3(256), 0, st,
-                           static_cast<const float*>(guidance), bs, cs, B, H, W, static_cast<float*>(w8), s_or_null);
+                           static_cast<const float*>(guidance), bs, cs, B, H, W, Wv, static_cast<float*>(w8), s_or_null);
     else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F16)
         hipLaunchKernelGGL((cspn3_prepare_kernel<__half, __half>), dim3(grid), dim3(256), 0, st,
-                           static_cast<const __half*>(guidance), bs, cs, B, H, W, static_cast<__half*>(w8), s_or_null);
+                           static_cast<const __half*>(guidance), bs, cs, B, H, W, Wv, static_cast<__half*>(w8), s_or_null);
     else if (g_dtype == CSPN_F16 && w_dtype == CSPN_F32)
         hipLaunchKernelGGL((cspn3_prepare_kernel<__half, float>), dim3(grid), dim3(256), 0, st,
-                           static_cast<const __half*>(guidance), bs, cs, B, H, W, static_cast<float*>(w8), s_or_null);
+                           static_cast<const __half*>(guidance), bs, cs, B, H, W, Wv, static_cast<float*>(w8), s_or_null);
     else
         return fail("cspn3_prepare: unsupported dtypes g=%d w=%d", g_dtype, w_dtype);
     HIP_OK(hipGetLastError());

@@ -34,6 +34,7 @@ struct PropArgs {
     const void* sparse;  // [B,H,W] (blend 1, 2)
     const void* d0;      // [B,H,W] (blend 1)
     int B, H, W, S;
+    int Wv;              // logical image width (<= W): columns [Wv, W) are row padding and are kept at exactly 0
     int tw, th, tiles_x, tiles_y;
     int wq, wr;          // weight region: quad columns, rows
     int hxw, hyw;        // weight-region halo (pixels) left/right, top/bottom
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     const int r0 = sy * NQ;                    // first weight-region row of this strip
     const int xq = x0 - a.hxw + 4 * sx;        // image x of the quad
     const int yq0 = y0 - a.hyw + r0;           // image y of the first quad
-    const bool x_in = (xq >= 0) && (xq < W);   // W % 4 == 0: a quad is fully inside or outside
+    const bool x_in = (xq >= 0) && (xq < a.Wv);   // W % 4 == 0: a quad lies inside the pitch or outside
+    const int nval = a.Wv - xq;                   // elements e < nval are inside the logical width (>= 4: all)
     const int lane = tid & 63;
     const bool fix_left = (sx == 0) || (lane == 0);          // left neighbour quad is not lane-1's
     const bool fix_right = (sx == wq - 1) || (lane == 63);   // right neighbour quad is not lane+1's
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                 for (int j = 0; j < 8; ++j) av[j] = wreg[i][j][e];
                 div8_shared_reciprocal(av, S, qv);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) wreg[i][j][e] = ok ? qv[j] : 0.f;
+                for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? qv[j] : 0.f;
             }
             // the launch that derives the weights can also publish them (tap-volume layout) for the launches
             // that follow, which then stream them like a prepared volume
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                         } else {
                             keep[e] = u[e];
                         }
-                        if (!((in_img >> i) & 1u)) { u[e] = 0.f; keep[e] = 0.f; }   // zero padding stays exactly zero
+                        // zero padding (outside the image, incl. row-padding columns) stays exactly zero
+                        if (!((in_img >> i) & 1u) || e >= nval) { u[e] = 0.f; keep[e] = 0.f; }
                     }
                     if (!last)
                         *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) =
@@ -407,11 +410,13 @@ struct Launch {
 };
 
 // Geometry of one fused launch.  Returns false if (plan, S) does not fit the machine limits.
-bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, int threads, int blend, Launch* L) {
+bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, int threads, int blend, Launch* L,
+                   int Wv = 0) {
     const int R = K / 2;
     if (tw <= 0 || th <= 0 || (tw & 3) || nq <= 0) return false;
     PropArgs& a = L->a;
     a.B = B; a.H = H; a.W = W; a.S = S;
+    a.Wv = (Wv > 0 && Wv < W) ? Wv : W;
     a.tw = tw; a.th = th;
     a.tiles_x = ceil_div(W, tw);
     a.tiles_y = ceil_div(H, th);
@@ -586,7 +591,9 @@ template <int K, typename WT, typename DT>
 int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
                     int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st,
                     int wsrc = 0, long g_bs = 0, long g_cs = 0, const void* target = nullptr, double* macc = nullptr,
-                    int nslots = 0, void* w_out = nullptr) {
+                    int nslots = 0, void* w_out = nullptr, int Wv = 0) {
+    if (Wv < 0 || Wv > W) return fail("W_valid=%d outside (0, W=%d]", Wv, W);
+    if (Wv > 0 && Wv < W && (W % 4 != 0)) return fail("row padding (W_valid < W) needs a pitch W %% 4 == 0");
     const size_t plane_bytes = (size_t)B * H * W * sizeof(DT);
     if (T == 0) {
         if (out) HIP_OK(hipMemcpyAsync(out, d0, plane_bytes, hipMemcpyDeviceToDevice, st));
@@ -618,7 +625,7 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
         }
         if (vec) {
             Launch L{};
-            if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, blend, &L))
+            if (!make_geometry(K, B, H, W, S, p.tile_w, p.tile_h, p.quads_per_thread, p.threads, blend, &L, Wv))
                 return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
                             p.quads_per_thread, p.threads);
             // from-guidance with a weight buffer: the first launch derives + publishes the weights, the rest stream them
@@ -636,6 +643,7 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
             L.a.nslots = nslots;
             if (!launch_fused<K, WT, DT>(L, blend, derive ? 1 : 0, st)) return 0;
         } else {
+            if (Wv > 0 && Wv < W) return fail("row padding (W_valid < W) needs the vector path (16-byte aligned tensors)");
             if (wsrc) return fail("from-guidance propagation needs W %% 4 == 0 and 16-byte aligned tensors; "
                                   "use cspn3_prepare + cspn_propagate");
             if (macc) return fail("scored propagation needs W %% 4 == 0 and 16-byte aligned tensors; use "
@@ -651,14 +659,17 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
 
 template <int K>
 int propagate_k(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* history,
-                void* work, int d_dtype, int B, int H, int W, int T, int blend, const cspn_plan* plan,
+                void* work, int d_dtype, int B, int H, int W, int Wv, int T, int blend, const cspn_plan* plan,
                 hipStream_t st) {
     if (w_dtype == CSPN_F32 && d_dtype == CSPN_F32)
-        return propagate_typed<K, float, float>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st);
+        return propagate_typed<K, float, float>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 0, 0, 0,
+                                                nullptr, nullptr, 0, nullptr, Wv);
     if (w_dtype == CSPN_F16 && d_dtype == CSPN_F16)
-        return propagate_typed<K, __half, __half>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st);
+        return propagate_typed<K, __half, __half>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 0, 0, 0,
+                                                  nullptr, nullptr, 0, nullptr, Wv);
     if (w_dtype == CSPN_F16 && d_dtype == CSPN_F32)
-        return propagate_typed<K, __half, float>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st);
+        return propagate_typed<K, __half, float>(w, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 0, 0, 0,
+                                                 nullptr, nullptr, 0, nullptr, Wv);
     return fail("unsupported dtype combination w=%d d=%d", w_dtype, d_dtype);
 }
 
@@ -689,22 +700,22 @@ size_t cspn_propagate_workspace_bytes(int B, int H, int W, int T, int d_dtype, i
 }
 
 int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* history,
-                   void* work, int d_dtype, int B, int H, int W, int K, int T, int blend, const cspn_plan* plan,
-                   cspn_stream_t stream) {
+                   void* work, int d_dtype, int B, int H, int W, int W_valid, int K, int T, int blend,
+                   const cspn_plan* plan, cspn_stream_t stream) {
     if (!w || !d0 || B <= 0 || H <= 0 || W <= 0 || T < 0) return fail("cspn_propagate: bad arguments");
     if (blend != CSPN_BLEND_NONE && !sparse) return fail("cspn_propagate: blend=%d needs sparse", blend);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (K) {
-        case 3: return propagate_k<3>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
-        case 5: return propagate_k<5>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
-        case 7: return propagate_k<7>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, T, blend, plan, st);
+        case 3: return propagate_k<3>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, W_valid, T, blend, plan, st);
+        case 5: return propagate_k<5>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, W_valid, T, blend, plan, st);
+        case 7: return propagate_k<7>(w, w_dtype, d0, sparse, out, history, work, d_dtype, B, H, W, W_valid, T, blend, plan, st);
         default: return fail("cspn_propagate: unsupported K=%d (3, 5, 7)", K);
     }
 }
 
 int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* work,
-                          int d_dtype, int B, int H, int W, int K, int T, int blend, const void* target, double* acc,
-                          int nslots, const cspn_plan* plan, cspn_stream_t stream) {
+                          int d_dtype, int B, int H, int W, int W_valid, int K, int T, int blend, const void* target,
+                          double* acc, int nslots, const cspn_plan* plan, cspn_stream_t stream) {
     if (!w || !d0 || !out || !target || !acc || nslots < 1 || B <= 0 || H <= 0 || W <= 0 || T < 1)
         return fail("cspn_propagate_scored: bad arguments");
     if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn_propagate_scored: blend %d", blend);
@@ -712,7 +723,8 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
     if (!aligned16(target)) return fail("cspn_propagate_scored: target must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define SCORED(KV, WTT, DTT) \
-    return propagate_typed<KV, WTT, DTT>(w, d0, sparse, out, nullptr, work, B, H, W, T, blend, plan, st, 0, 0, 0, target, acc, nslots)
+    return propagate_typed<KV, WTT, DTT>(w, d0, sparse, out, nullptr, work, B, H, W, T, blend, plan, st, 0, 0, 0, target, acc, \
+                                         nslots, nullptr, W_valid)
     if (K == 3 && w_dtype == CSPN_F32 && d_dtype == CSPN_F32) SCORED(3, float, float);
     if (K == 3 && w_dtype == CSPN_F16 && d_dtype == CSPN_F16) SCORED(3, __half, __half);
     if (K == 5 && w_dtype == CSPN_F32 && d_dtype == CSPN_F32) SCORED(5, float, float);
@@ -723,7 +735,7 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
 
 int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, void* w8_out, const void* d0,
                                   const void* sparse, void* out, void* history, void* work, int d_dtype, int B, int H,
-                                  int W, int T, int blend, const void* target, double* acc, int nslots,
+                                  int W, int W_valid, int T, int blend, const void* target, double* acc, int nslots,
                                   const cspn_plan* plan, cspn_stream_t stream) {
     if ((target || acc) && (!target || !acc || nslots < 1 || !w8_out || history || !aligned16(target) || g_dtype != d_dtype))
         return fail("cspn3_propagate_from_guidance: scoring needs target, acc, nslots >= 1, w8_out, no history, "
@@ -735,11 +747,11 @@ int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, lo
     if (w8_out && !aligned16(w8_out)) return fail("cspn3_propagate_from_guidance: w8_out must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g_dtype == CSPN_F32 && d_dtype == CSPN_F32)
-        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out);
+        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid);
     if (g_dtype == CSPN_F16 && d_dtype == CSPN_F16)
-        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out);
+        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid);
     if (g_dtype == CSPN_F16 && d_dtype == CSPN_F32)
-        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out);
+        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid);
     return fail("cspn3_propagate_from_guidance: unsupported dtypes g=%d d=%d", g_dtype, d_dtype);
 }
 

@@ -219,7 +219,7 @@ def _weight_buffer(B, NT, H, W, dtype, device):
 
 
 # ------------------------------------------------------------------------------------------------ raw ops
-def cspn3_prepare(guidance, want_s=False, w_dtype=None):
+def cspn3_prepare(guidance, want_s=False, w_dtype=None, valid_w=0):
     """|g| -> shift -> /S: the 8 normalised weight planes of the 3x3 variant (CSPN_new.py:29-70,:124-127).
 
     Reads channels 0..7 of a [B,C>=8,H,W] guidance in place (C=12 from unet_cspn_nyu.py:332)."""
@@ -232,8 +232,8 @@ def cspn3_prepare(guidance, want_s=False, w_dtype=None):
     w8 = _weight_buffer(B, 8, H, W, w_dtype, dev)
     S = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_s else None
     with _device_guard(dev):
-        ok = _lib.lib().cspn3_prepare(_p(g), _dt(g), g.stride(0), g.stride(1), B, H, W, _p(w8), _dt(w8), _p(S),
-                                      _stream(dev))
+        ok = _lib.lib().cspn3_prepare(_p(g), _dt(g), g.stride(0), g.stride(1), B, H, W, int(valid_w), _p(w8), _dt(w8),
+                                      _p(S), _stream(dev))
     _lib.check(ok, "cspn3_prepare")
     return w8, S, g
 
@@ -258,7 +258,7 @@ def pac_prepare(guided, w_dtype=None):
     return wk, K
 
 
-def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
+def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None, valid_w=0):
     """T steps of d <- blend(sum_j w_j * d[.+off_j]).  w: tap volume from cspn3_prepare / pac_prepare /
     transpose_weights (see _weight_buffer); d0, sparse [B,H,W].
 
@@ -296,7 +296,7 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None):
             ev0, ev1 = log.pair()
             ev0.record(torch.cuda.current_stream(dev))
         ok = L.cspn_propagate(_p(w), _dt(w), _p(d0), _p(sparse), _p(out), _p(hist), _p(work), _dt(d0),
-                              B, H, W, int(K), T, int(blend), _plan_ptr(K, plan), _stream(dev))
+                              B, H, W, int(valid_w), int(K), T, int(blend), _plan_ptr(K, plan), _stream(dev))
         if log is not None:
             ev1.record(torch.cuda.current_stream(dev))
             key = (K, B, H, W, T, keep_history, id(plan))
@@ -325,7 +325,7 @@ def scored_supported(w, d0, sparse, target, K, T, plan=None):
     return not p["force_scalar"] and (p["quads_per_thread"], p["threads"]) in _SCORED_INSTANCES[K]
 
 
-def propagate_scored(w, d0, sparse, K, T, blend, target, acc, plan=None):
+def propagate_scored(w, d0, sparse, K, T, blend, target, acc, plan=None, valid_w=0):
     """propagate() whose final launch also adds the depth metrics of d_T vs `target` [B,H,W] into `acc`
     (evaluation.new_accumulator): the refined batch is not re-read by a separate metrics pass."""
     dev = _require_device(w, d0, sparse, target)
@@ -343,9 +343,9 @@ def propagate_scored(w, d0, sparse, K, T, blend, target, acc, plan=None):
         if log is not None:
             ev0, ev1 = log.pair()
             ev0.record(torch.cuda.current_stream(dev))
-        ok = L.cspn_propagate_scored(_p(w), _dt(w), _p(d0), _p(sparse), _p(out), _p(work), _dt(d0), B, H, W, int(K),
-                                     int(T), int(blend), _p(target), _p(acc), int(acc.shape[0]), _plan_ptr(K, plan),
-                                     _stream(dev))
+        ok = L.cspn_propagate_scored(_p(w), _dt(w), _p(d0), _p(sparse), _p(out), _p(work), _dt(d0), B, H, W,
+                                     int(valid_w), int(K), int(T), int(blend), _p(target), _p(acc), int(acc.shape[0]),
+                                     _plan_ptr(K, plan), _stream(dev))
         if log is not None:
             ev1.record(torch.cuda.current_stream(dev))
             key = (K, B, H, W, T, False, id(plan))
@@ -377,7 +377,7 @@ def from_guidance_supported(guidance, d0, sparse, plan=None):
 
 
 def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, plan=None, publish_weights=True,
-                            score=None):
+                            score=None, valid_w=0):
     """3x3 variant without a prepare pass: every launch derives the normalised weights from `guidance`
     (cspn3_propagate_from_guidance).  Same results, bit for bit, as cspn3_prepare + propagate."""
     dev = _require_device(guidance, d0, sparse)
@@ -407,7 +407,7 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
         w8 = _weight_buffer(B, 8, H, W, g.dtype, dev) if publish_weights else None
         tg, acc = score if score is not None else (None, None)
         ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(w8), _p(d0), _p(sparse), _p(out),
-                                             _p(hist), _p(work), _dt(d0), B, H, W, T, int(blend),
+                                             _p(hist), _p(work), _dt(d0), B, H, W, int(valid_w), T, int(blend),
                                              _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                              _plan_ptr(3, plan), _stream(dev))
         if log is not None:
@@ -430,7 +430,7 @@ def transpose_weights(w, K, H, W):
     return wT
 
 
-def _reverse_sweep(w, K, T, sparse, grad_out, plan):
+def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
     """G_T = dL/dout, G_t = stencil^T((1-m) G_{t+1}): the forward kernel on the transposed weights.
     Returns ghist [T+1,B,H,W] f32 in backward order (ghist[s] = G_{T-s})."""
     dev = w.device
@@ -442,7 +442,7 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan):
         wT = transpose_weights(w, K, H, W)
         with _device_guard(dev):
             ok = _lib.lib().cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
-                                           CSPN_F32, B, H, W, int(K), T,
+                                           CSPN_F32, B, H, W, int(valid_w), int(K), T,
                                            BLEND_PREMASK if sparse is not None else BLEND_NONE,
                                            _plan_ptr(K, plan), _stream(dev))
         _lib.check(ok, "cspn_propagate(backward)")
@@ -469,14 +469,14 @@ def _grad_weights(w, K, T, d0, dhist, sparse, ghist):
 # ------------------------------------------------------------------------------------------------ autograd
 class _NoGradCtx(object):
     """Stand-in ctx for inference calls that skip torch.autograd.Function.apply (saves ~10 us of host time)."""
-    needs_input_grad = (False, False, False, False, False, False)
+    needs_input_grad = (False,) * 8
 
 
 class CSPN3Function(torch.autograd.Function):
     """3x3 variant, forward + hand-written backward (SURVEY.md §3.2 closed form)."""
 
     @staticmethod
-    def forward(ctx, guidance, blur_depth, sparse_depth, prop_time, plan):
+    def forward(ctx, guidance, blur_depth, sparse_depth, prop_time, plan, valid_w=0):
         B, C, H, W = guidance.shape
         d0 = _plane(blur_depth, B, H, W, "blur_depth")
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
@@ -486,13 +486,13 @@ class CSPN3Function(torch.autograd.Function):
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
         if not need_grad and _FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan):
             # inference: no separate prepare pass (the first launch derives and publishes the weights)
-            out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan)
+            out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, valid_w=valid_w)
             return out.unsqueeze(1)
-        w8, S, g = cspn3_prepare(guidance, want_s=need_grad)
-        out, hist = propagate(w8, d0, sp, 3, prop_time, blend, keep_history=need_grad, plan=plan)
+        w8, S, g = cspn3_prepare(guidance, want_s=need_grad, valid_w=valid_w)
+        out, hist = propagate(w8, d0, sp, 3, prop_time, blend, keep_history=need_grad, plan=plan, valid_w=valid_w)
         if need_grad:
             ctx.save_for_backward(g, w8, S, d0, sp, hist)
-            ctx.prop_time, ctx.plan = int(prop_time), plan
+            ctx.prop_time, ctx.plan, ctx.valid_w = int(prop_time), plan, int(valid_w)
             ctx.in_shape = tuple(blur_depth.shape)
         return out.unsqueeze(1)
 
@@ -502,7 +502,7 @@ class CSPN3Function(torch.autograd.Function):
         B, C, H, W = g.shape
         T = ctx.prop_time
         L = _lib.lib()
-        ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan)
+        ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
         gg = torch.empty_like(g)
         if _tail_vector_ok(W, g, w8, S, d0, sp, hist, gg) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
             gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)
@@ -519,14 +519,14 @@ class CSPN3Function(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             gg = None
         gd = gd0.to(d0.dtype).reshape(ctx.in_shape) if ctx.needs_input_grad[1] else None
-        return gg, gd, None, None, None
+        return gg, gd, None, None, None, None
 
 
 class PACFunction(torch.autograd.Function):
     """K x K softmax variant (CSPN_ours.py / pac.py) forward + backward."""
 
     @staticmethod
-    def forward(ctx, x, guided, sparse_depth, prop_time, plan, state_dtype):
+    def forward(ctx, x, guided, sparse_depth, prop_time, plan, state_dtype, valid_w=0):
         B, C, H, W = guided.shape
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError("x must be [B,1,H,W] (the depth map); got %s" % (tuple(x.shape),))
@@ -537,10 +537,10 @@ class PACFunction(torch.autograd.Function):
         sp = None if sp is None else sp.to(sdt)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         out, hist = propagate(wk, d0, sp, K, prop_time, BLEND_SPARSE if sp is not None else BLEND_NONE,
-                              keep_history=need_grad, plan=plan)
+                              keep_history=need_grad, plan=plan, valid_w=valid_w)
         if need_grad:
             ctx.save_for_backward(wk, d0, sp, hist)
-            ctx.K, ctx.prop_time, ctx.plan = K, int(prop_time), plan
+            ctx.K, ctx.prop_time, ctx.plan, ctx.valid_w = K, int(prop_time), plan, int(valid_w)
             ctx.x_dtype, ctx.g_dtype = x.dtype, guided.dtype
         return out.unsqueeze(1)
 
@@ -551,7 +551,7 @@ class PACFunction(torch.autograd.Function):
         K, T = ctx.K, ctx.prop_time
         NT = K * K - 1
         L = _lib.lib()
-        ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan)
+        ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
         gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
         if _tail_vector_ok(W, wk, d0, sp, hist, gg):
             gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
@@ -567,7 +567,7 @@ class PACFunction(torch.autograd.Function):
         if not ctx.needs_input_grad[1]:
             gg = None
         gx = gx0.to(ctx.x_dtype).unsqueeze(1) if ctx.needs_input_grad[0] else None
-        return gx, gg, None, None, None, None
+        return gx, gg, None, None, None, None, None
 
 
 def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop_time=24, plan=None):
@@ -576,6 +576,12 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
     (libs/trainers/single_gpu_trainer.py:129-140) with the metrics fused into the last propagation launch."""
     from . import evaluation
     dev = _require_device(guidance, blur_depth, sparse_depth, target)
+    W0 = guidance.shape[-1]
+    pad = _row_padding(W0, plan)
+    if pad:
+        guidance, blur_depth, sparse_depth, target = (_pad_w(t, pad) for t in (guidance[:, :8], blur_depth, sparse_depth,
+                                                                               target))
+    vw = W0 if pad else 0
     B, C, H, W = guidance.shape
     d0 = _plane(blur_depth, B, H, W, "blur_depth")
     sp = _plane(sparse_depth, B, H, W, "sparse_depth")
@@ -587,22 +593,28 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
             p = resolve_plan(3, B, H, W, prop_time, False, plan)
             if (prop_time > p["steps_per_launch"] and not p["force_scalar"]
                     and (p["quads_per_thread"], p["threads"]) in _SCORED_INSTANCES[3]):
-                out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, score=(tg, acc))
-                return out.unsqueeze(1)
-        w8, _, _ = cspn3_prepare(guidance)
+                out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, score=(tg, acc),
+                                                 valid_w=vw)
+                return out.unsqueeze(1)[..., :W0]
+        w8, _, _ = cspn3_prepare(guidance, valid_w=vw)
         if scored_supported(w8, d0, sp, tg, 3, prop_time, plan):
-            out = propagate_scored(w8, d0, sp, 3, prop_time, blend, tg, acc, plan)
+            out = propagate_scored(w8, d0, sp, 3, prop_time, blend, tg, acc, plan, valid_w=vw)
         else:
-            out, _ = propagate(w8, d0, sp, 3, prop_time, blend, plan=plan)
+            out, _ = propagate(w8, d0, sp, 3, prop_time, blend, plan=plan, valid_w=vw)
             evaluation.metric_sums(out, tg, out=acc)
     del dev
-    return out.unsqueeze(1)
+    return out.unsqueeze(1)[..., :W0]
 
 
 def pac_refine_and_score(x, guided, sparse_depth, target, acc, prop_time=24, plan=None, state_dtype=None):
     """K x K twin of cspn3_refine_and_score."""
     from . import evaluation
     _require_device(x, guided, sparse_depth, target)
+    W0 = guided.shape[-1]
+    pad = _row_padding(W0, plan)
+    if pad:
+        x, guided, sparse_depth, target = (_pad_w(t, pad) for t in (x, guided, sparse_depth, target))
+    vw = W0 if pad else 0
     B, C, H, W = guided.shape
     with torch.no_grad():
         wk, K = pac_prepare(guided)
@@ -613,24 +625,55 @@ def pac_refine_and_score(x, guided, sparse_depth, target, acc, prop_time=24, pla
         tg = _plane(target, B, H, W, "target").to(sdt)
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
         if scored_supported(wk, d0, sp, tg, K, prop_time, plan):
-            out = propagate_scored(wk, d0, sp, K, prop_time, blend, tg, acc, plan)
+            out = propagate_scored(wk, d0, sp, K, prop_time, blend, tg, acc, plan, valid_w=vw)
         else:
-            out, _ = propagate(wk, d0, sp, K, prop_time, blend, plan=plan)
+            out, _ = propagate(wk, d0, sp, K, prop_time, blend, plan=plan, valid_w=vw)
             evaluation.metric_sums(out, tg, out=acc)
-    return out.unsqueeze(1)
+    return out.unsqueeze(1)[..., :W0]
+
+
+def _row_padding(W, plan):
+    """Columns to append so that rows are whole quads (0 when W % 4 == 0 or the plan forces the generic kernels).
+    The padded columns are passed to the engine as row padding (W_valid), i.e. treated as outside the image."""
+    if W % 4 == 0 or (isinstance(plan, dict) and plan.get("force_scalar")):
+        return 0
+    forced = _DEFAULT_PLANS.get(3)
+    if plan is None and isinstance(forced, dict) and forced.get("force_scalar"):
+        return 0
+    return -W % 4
+
+
+def _pad_w(t, pad):
+    return None if t is None else torch.nn.functional.pad(t, (0, pad))
 
 
 def cspn3_affinity_propagate(guidance, blur_depth, sparse_depth=None, prop_time=24, plan=None):
     """Functional form of CSPN_new.AffinityPropagate.forward (CSPN_new.py:26-92)."""
     _require_device(guidance, blur_depth, sparse_depth)
+    W = guidance.shape[-1]
+    pad = _row_padding(W, plan)
+    if pad:     # any width: zero-pad the rows to whole quads and tell the engine the true width
+        # (only the 8 channels the module reads are copied; the others get a zero gradient from the slice)
+        guidance, blur_depth, sparse_depth = (_pad_w(guidance[:, :8], pad), _pad_w(blur_depth, pad),
+                                              _pad_w(sparse_depth, pad))
+    vw = W if pad else 0
     if not (torch.is_grad_enabled() and (guidance.requires_grad or blur_depth.requires_grad)):
-        return CSPN3Function.forward(_NoGradCtx, guidance, blur_depth, sparse_depth, int(prop_time), plan)
-    return CSPN3Function.apply(guidance, blur_depth, sparse_depth, int(prop_time), plan)
+        out = CSPN3Function.forward(_NoGradCtx, guidance, blur_depth, sparse_depth, int(prop_time), plan, vw)
+    else:
+        out = CSPN3Function.apply(guidance, blur_depth, sparse_depth, int(prop_time), plan, vw)
+    return out[..., :W] if pad else out
 
 
 def pac_affinity_propagate(x, guided, sparse_depth=None, prop_time=24, plan=None, state_dtype=None):
     """Functional form of CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54)."""
     _require_device(x, guided, sparse_depth)
+    W = guided.shape[-1]
+    pad = _row_padding(W, plan)
+    if pad:
+        x, guided, sparse_depth = _pad_w(x, pad), _pad_w(guided, pad), _pad_w(sparse_depth, pad)
+    vw = W if pad else 0
     if not (torch.is_grad_enabled() and (x.requires_grad or guided.requires_grad)):
-        return PACFunction.forward(_NoGradCtx, x, guided, sparse_depth, int(prop_time), plan, state_dtype)
-    return PACFunction.apply(x, guided, sparse_depth, int(prop_time), plan, state_dtype)
+        out = PACFunction.forward(_NoGradCtx, x, guided, sparse_depth, int(prop_time), plan, state_dtype, vw)
+    else:
+        out = PACFunction.apply(x, guided, sparse_depth, int(prop_time), plan, state_dtype, vw)
+    return out[..., :W] if pad else out

@@ -21,6 +21,13 @@
  * Tensor layout: NCHW contiguous planes.  "taps" are the K*K-1 non-centre offsets (dy,dx) in
  * row-major order over [-K/2, K/2]^2; tap j of a weight volume multiplies depth[p + off_j].
  *
+ * Row padding.  The 16-byte quad kernels need W % 4 == 0.  Images of any other width are handled by the caller
+ * zero-padding every row to the next multiple of 4 and passing the true width as `W_valid` (0 or W = no padding):
+ * columns [W_valid, W) are then treated exactly like pixels outside the image — zero gate, zero depth, forced to
+ * 0 after every step — which is the reference's own boundary condition, so in-image results are unchanged.
+ * (Plain zero padding WITHOUT W_valid is not equivalent: pad pixels with an all-zero neighbourhood become 0/0.)
+ * With W % 4 != 0 and no padding the library falls back to generic one-pixel-per-thread kernels.
+ *
  * Tap-volume layout (the `w8` / `wk` / `wT` buffers; produced and consumed only by this library):
  *   CSPN_F32: planar [B, NT, H, W], NT = K*K-1.
  *   CSPN_F16: tap PAIRS interleaved per 4-pixel quad, [B, NT/2, ceil(H*W/4), 2, 4] halfs (B*NT*ceil4(H*W)
@@ -36,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 1
+#define CSPN_ABI_VERSION 2
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -76,7 +83,7 @@ int cspn_plan_resolve(int K, int B, int H, int W, int T, int keep_history, const
  * channels of the UNet's 12-channel head (unet_cspn_nyu.py:332) are used in place.
  * w8: [B,8,H,W] of w_dtype.  s_or_null: optional [B,H,W] f32 receiving the normaliser S. */
 int cspn3_prepare(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
-                  int B, int H, int W, void* w8, int w_dtype, float* s_or_null, cspn_stream_t stream);
+                  int B, int H, int W, int W_valid, void* w8, int w_dtype, float* s_or_null, cspn_stream_t stream);
 
 /* ---- K x K, centre-indexed softmax variant (CSPN_ours.py + pac.py) -------------------------- */
 
@@ -97,7 +104,7 @@ size_t cspn_propagate_workspace_bytes(int B, int H, int W, int T, int d_dtype, i
  * Replaces the 24x {8 pads, cat, mul, 2 conv3d, div, crop, blend} loop at CSPN_new.py:80-90 and the
  * unfold/mul/einsum loop at CSPN_ours.py:47-53 / pac.py:89-92. */
 int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* sparse, void* out,
-                   void* history, void* work, int d_dtype, int B, int H, int W, int K, int T,
+                   void* history, void* work, int d_dtype, int B, int H, int W, int W_valid, int K, int T,
                    int blend, const cspn_plan* plan, cspn_stream_t stream);
 
 /* cspn_propagate + cspn_metrics_accumulate in one: the launch that produces d_T also accumulates the depth
@@ -106,8 +113,8 @@ int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* spars
  * tap volume, K in {3,5}, w_dtype == d_dtype, W % 4 == 0 and 16-byte aligned tensors, a plan with one quad per
  * thread (the built-in plans); returns 0 otherwise and the caller uses the two-call form. */
 int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* work,
-                          int d_dtype, int B, int H, int W, int K, int T, int blend, const void* target,
-                          double* acc, int nslots, const cspn_plan* plan, cspn_stream_t stream);
+                          int d_dtype, int B, int H, int W, int W_valid, int K, int T, int blend,
+                          const void* target, double* acc, int nslots, const cspn_plan* plan, cspn_stream_t stream);
 
 /* 3x3 variant, inference: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
  * weights from the raw guidance (same arithmetic, bit-identical results), so the 8 weight planes are never
@@ -121,7 +128,7 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
  * blend: CSPN_BLEND_NONE or CSPN_BLEND_SPARSE.  Replaces all of CSPN_new.py:29-92 for a forward pass. */
 int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
                                   void* w8_out_or_null, const void* d0, const void* sparse, void* out, void* history, void* work,
-                                  int d_dtype, int B, int H, int W, int T, int blend,
+                                  int d_dtype, int B, int H, int W, int W_valid, int T, int blend,
                                   const void* target_or_null, double* acc_or_null, int nslots,
                                   const cspn_plan* plan, cspn_stream_t stream);
 

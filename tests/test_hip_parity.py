@@ -32,7 +32,7 @@ def run3(g, d, s, T, plan=None):
 
 
 def test_native_library_is_loaded():
-    assert _lib.lib().cspn_abi_version() == 1
+    assert _lib.lib().cspn_abi_version() == 2
     maps = open("/proc/self/maps").read()
     assert "libcspn_hip.so" in maps
 
@@ -442,3 +442,50 @@ def test_graphed_forward_helper(c_oracle):
     out2 = graphed(gt, dt * 0.5, st * 0.5, tt)         # fresh inputs are copied into the captured buffers
     torch.cuda.synchronize()
     assert torch.allclose(out2, 0.5 * ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("W", [17, 65, 207, 3, 1])
+def test_any_width_row_padding_is_exact(W, c_oracle):
+    """Widths with W % 4 != 0 run on the quad kernels through row padding (W_valid): bit-identical to the
+    generic one-pixel-per-thread kernels for the 3x3 variant, oracle parity for both variants, NaN semantics
+    of degenerate shapes preserved, gradients correct through the padding."""
+    B, H, T = 2, 23, 9
+    g, d, s = c_oracle.synthetic_inputs(81, B, H, W, 12, max(2, H * W // 20))
+    vec, gen = pkg.CSPN_new.AffinityPropagate(T, 3), pkg.CSPN_new.AffinityPropagate(T, 3, plan=dict(force_scalar=1))
+    for sp in (None, s):
+        want = c_oracle.cspn3_forward(g, d, sp, T)
+        with torch.no_grad():
+            a, b = vec(dev(g), dev(d), dev(sp)), gen(dev(g), dev(d), dev(sp))
+        assert a.shape == (B, 1, H, W) and a.is_contiguous() is not None
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        assert rel_err(a.cpu().numpy(), want) <= REL_TOL
+    if W >= 3:
+        gt, dt = dev(g).requires_grad_(True), dev(d).requires_grad_(True)
+        cot = c_oracle.hash_normal(82, 9, (B, 1, H, W))
+        vec(gt, dt, dev(s)).backward(dev(cot))
+        wg, wd = c_oracle.cspn3_backward(g, d, s, cot, T, np.float64)
+        assert gt.grad.shape == gt.shape and dt.grad.shape == dt.shape
+        assert np.abs(gt.grad.cpu().numpy() - wg).max() <= 5e-4 * max(1.0, np.abs(wg).max())
+        assert np.abs(dt.grad.cpu().numpy() - wd).max() <= 5e-5 * max(1.0, np.abs(wd).max())
+        # scored forward on an odd width
+        tgt = np.maximum(d + 0.1 * c_oracle.hash_normal(84, 9, d.shape), 0.0).astype(np.float32)
+        acc = pkg.evaluation.new_accumulator(DEV)
+        with torch.no_grad():
+            ref = vec(dev(g), dev(d), dev(s))
+            out = vec.forward_scored(dev(g), dev(d), dev(s), dev(tgt), acc)
+            want_m = pkg.evaluation.metric_sums(ref, dev(tgt))
+        assert torch.equal(out, ref) and np.allclose(acc.sum(0).cpu().numpy(), want_m.cpu().numpy(), rtol=1e-5)
+    # K x K
+    gd = c_oracle.hash_normal(83, 1, (B, 24, H, W)); x = c_oracle.hash_uniform(83, 2, (B, 1, H, W), 0.0, 10.0)
+    for sp in (None, c_oracle.hash_sparse(83, 3, x, 0.05)):
+        want = c_oracle.pac_forward(x, gd, sp, 6)
+        with torch.no_grad():
+            out = pkg.CSPN_ours.AffinityPropagate(6)(dev(x), dev(gd), sparse_depth=dev(sp))
+        assert out.shape == (B, 1, H, W) and rel_err(out.cpu().numpy(), want) <= REL_TOL
+    if W >= 3:
+        xt, gdt = dev(x).requires_grad_(True), dev(gd).requires_grad_(True)
+        cot = c_oracle.hash_normal(85, 9, (B, 1, H, W))
+        pkg.CSPN_ours.AffinityPropagate(4)(xt, gdt).backward(dev(cot))
+        wx, wgd = orc.pac_backward(x, gd, None, cot, 4, np.float64)
+        assert np.abs(xt.grad.cpu().numpy() - wx).max() <= 5e-5 * max(1.0, np.abs(wx).max())
+        assert np.abs(gdt.grad.cpu().numpy() - wgd).max() <= 5e-4 * max(1.0, np.abs(wgd).max())
