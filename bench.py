@@ -253,6 +253,10 @@ def main():
     elapsed = float(elapsed.item())
 
     # ---- roofline of the dominant kernel (the propagation kernel), from HIP events on the launch stream
+    per_fwd_us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1, _, _ in events)      # one entry per timed step
+
+    def pct(q):
+        return per_fwd_us[min(len(per_fwd_us) - 1, int(q * len(per_fwd_us)))] if per_fwd_us else None
     prop_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in events)
     n_launch = sum(n for _, _, n, _ in events)
     S = eff_plan["steps_per_launch"]
@@ -416,6 +420,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_timed": n_launch,
                          "steps_per_launch": S, "bytes_per_px_step": bytes_px_step,
+                         "propagation_us_per_step_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)],
                          "note": "HIP events around each propagation loop inside the timed region (launch gaps "
                                  "included) / launches; S>1 = temporal blocking, so algorithmic bytes per launch "
                                  "exceed what the launch reads from HBM"},
