@@ -25,7 +25,7 @@ BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
-    "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn3_propagate_from_guidance",
+    "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn_propagate_transposed", "cspn3_propagate_from_guidance",
     "cspn_transpose_weights",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
@@ -92,6 +92,7 @@ def _declare(lib):
                                    ctypes.POINTER(cspn_plan), vp]
     lib.cspn_propagate_scored.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci,
                                           ctypes.POINTER(cspn_plan), vp]
+    lib.cspn_propagate_transposed.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_plan), vp]
     lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
                                                   vp, vp, ci,
                                                   ctypes.POINTER(cspn_plan), vp]

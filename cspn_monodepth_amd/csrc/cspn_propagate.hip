@@ -53,7 +53,7 @@ template <int K, int NQ> struct MinWaves { static constexpr int value = (K == 3 
 // against `target` (the reduction cspn_metrics_kernel would do in a separate pass over the output).
 template <int K, int NQ, int NTHREADS, typename WT, typename DT, int BLEND, int WSRC, int SCORE = 0>
 __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_fused(const PropArgs a) {
-    static_assert(WSRC == 0 || K == 3, "on-the-fly weights exist for the 3x3 variant only");
+    static_assert(WSRC != 1 || K == 3, "on-the-fly weights exist for the 3x3 variant only");
     constexpr int R = K / 2;
     constexpr int NT = K * K - 1;
     constexpr int WIN = 4 + 2 * R;
@@ -106,6 +106,71 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (WSRC == 0) {
             load_taps_quad<NT>(wg, off, HW, ok, wreg[i]);
+        } else if constexpr (WSRC == 2) {
+            // Transposed stencil (backward recurrence): tap j = w_{NT-1-j}[p + off_j], read straight from the
+            // forward tap volume — one aligned quad of plane NT-1-j at row y+dy, shifted by dx columns with the
+            // neighbouring lanes' quads (DPP), strip-end lanes patch with scalar loads.  No transposed copy of
+            // the weights ever exists.
+            float lq[NT][R], rq[NT][R];      // lq[j][c] = column xq-R+c, rq[j][c] = column xq+4+c of the source row
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int lin = j < NT / 2 ? j : j + 1;
+                const int dy = lin / K - R;
+                const int row = y + dy;
+                const bool rok = ok && row >= 0 && row < H;
+                const float4 v = rok ? ld4(wg + Taps<WT>::idx(NT - 1 - j, (size_t)(rok ? row : 0) * W + xq, HW)) : z4;
+                wreg[i][j][0] = v.x; wreg[i][j][1] = v.y; wreg[i][j][2] = v.z; wreg[i][j][3] = v.w;
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    lq[j][c] = dpp_from_prev_lane(wreg[i][j][4 - R + c]);
+                    rq[j][c] = dpp_from_next_lane(wreg[i][j][c]);
+                }
+            }
+            if (fix_left) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int lin = j < NT / 2 ? j : j + 1;
+                    const int dy = lin / K - R, dx = lin % K - R;
+                    const int row = y + dy;
+                    if (dx < 0) {
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            const int xx = xq - R + c;
+                            const bool cnd = ok && row >= 0 && row < H && xx >= 0;
+                            lq[j][c] = cnd ? ld1(wg + Taps<WT>::idx(NT - 1 - j, (size_t)row * W + xx, HW)) : 0.f;
+                        }
+                    }
+                }
+            }
+            if (fix_right) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int lin = j < NT / 2 ? j : j + 1;
+                    const int dy = lin / K - R, dx = lin % K - R;
+                    const int row = y + dy;
+                    if (dx > 0) {
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            const int xx = xq + 4 + c;
+                            const bool cnd = ok && row >= 0 && row < H && xx < W;
+                            rq[j][c] = cnd ? ld1(wg + Taps<WT>::idx(NT - 1 - j, (size_t)row * W + xx, HW)) : 0.f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int lin = j < NT / 2 ? j : j + 1;
+                const int dx = lin % K - R;
+                // window of the source row: [xq-R, xq+4+R) = lq | own quad | rq; tap value e = window[R + e + dx]
+                float win[4 + 2 * R];
+#pragma unroll
+                for (int c = 0; c < R; ++c) { win[c] = lq[j][c]; win[R + 4 + c] = rq[j][c]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) win[R + e] = wreg[i][j][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wreg[i][j][e] = ok ? win[R + e + dx] : 0.f;
+            }
         } else {
             // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j.  The aligned quad of
             // row y+dy gives three of the four shifted values, the fourth is the neighbouring lane's quad
@@ -542,7 +607,7 @@ int launch_fused(const Launch& L, int blend, int wsrc, hipStream_t st) {
         return fail("no scoring kernel instance for K=%d quads_per_thread=%d threads=%d", K, L.nq, L.threads);
     }
     if constexpr (K == 3) {
-        if (wsrc) {      // on-the-fly weights: one- and two-quad instances only
+        if (wsrc == 1) { // on-the-fly weights: one- and two-quad instances only
 #define CSPN_CASE_G(NQV, NTV) \
     if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT, 1>(L, blend, st)
             CSPN_CASE_G(1, 256); CSPN_CASE_G(2, 256); CSPN_CASE_G(1, 512); CSPN_CASE_G(2, 512);
@@ -550,8 +615,19 @@ int launch_fused(const Launch& L, int blend, int wsrc, hipStream_t st) {
 #undef CSPN_CASE_G
             return fail("no from-guidance kernel instance for quads_per_thread=%d threads=%d", L.nq, L.threads);
         }
-    } else if (wsrc) {
+    } else if (wsrc == 1) {
         return fail("on-the-fly weights exist for K=3 only");
+    }
+    if (wsrc == 2) {     // transposed recurrence: one-quad (and, K=3, two-quad) instances, f32 state
+        if constexpr (std::is_same<DT, float>::value) {
+#define CSPN_CASE_T(NQV, NTV) \
+    if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT, 2>(L, blend, st)
+            CSPN_CASE_T(1, 256);
+            if constexpr (K <= 5) { CSPN_CASE_T(1, 512); }
+            if constexpr (K == 3) { CSPN_CASE_T(2, 256); CSPN_CASE_T(2, 512); CSPN_CASE_T(1, 1024); CSPN_CASE_T(2, 1024); }
+#undef CSPN_CASE_T
+        }
+        return fail("no transposed kernel instance for K=%d quads_per_thread=%d threads=%d", K, L.nq, L.threads);
     }
 #define CSPN_CASE(NQV, NTV) \
     if (L.nq == NQV && L.threads == NTV) return launch_fused_blend<K, NQV, NTV, WT, DT, 0>(L, blend, st)
@@ -629,8 +705,8 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
                 return fail("plan does not fit: K=%d S=%d tile=%dx%d nq=%d threads=%d", K, S, p.tile_w, p.tile_h,
                             p.quads_per_thread, p.threads);
             // from-guidance with a weight buffer: the first launch derives + publishes the weights, the rest stream them
-            const bool derive = wsrc && (launch_idx == 0 || !w_out);
-            L.a.w = (wsrc && !derive) ? w_out : w;
+            const bool derive = (wsrc == 1) && (launch_idx == 0 || !w_out);
+            L.a.w = (wsrc == 1 && !derive) ? w_out : w;
             L.a.w_out = (derive && n_launch > 1) ? w_out : nullptr;
             L.a.g_bs = g_bs; L.a.g_cs = g_cs; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
             L.a.d_out = history ? nullptr : dst;
@@ -641,9 +717,11 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
             L.a.target = final_launch ? target : nullptr;
             L.a.macc = final_launch ? macc : nullptr;
             L.a.nslots = nslots;
-            if (!launch_fused<K, WT, DT>(L, blend, derive ? 1 : 0, st)) return 0;
+            if (!launch_fused<K, WT, DT>(L, blend, wsrc == 2 ? 2 : (derive ? 1 : 0), st)) return 0;
         } else {
             if (Wv > 0 && Wv < W) return fail("row padding (W_valid < W) needs the vector path (16-byte aligned tensors)");
+            if (wsrc == 2) return fail("transposed propagation needs W %% 4 == 0 and 16-byte aligned tensors; use "
+                                       "cspn_transpose_weights + cspn_propagate");
             if (wsrc) return fail("from-guidance propagation needs W %% 4 == 0 and 16-byte aligned tensors; "
                                   "use cspn3_prepare + cspn_propagate");
             if (macc) return fail("scored propagation needs W %% 4 == 0 and 16-byte aligned tensors; use "
@@ -731,6 +809,29 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
     if (K == 5 && w_dtype == CSPN_F16 && d_dtype == CSPN_F16) SCORED(5, __half, __half);
 #undef SCORED
     return fail("cspn_propagate_scored: unsupported K=%d / dtypes w=%d d=%d", K, w_dtype, d_dtype);
+}
+
+int cspn_propagate_transposed(const void* w, int w_dtype, const float* g_T, const float* sparse_f32, float* history,
+                              int B, int H, int W, int W_valid, int K, int T, int premask, const cspn_plan* plan,
+                              cspn_stream_t stream) {
+    if (!w || !g_T || !history || B <= 0 || H <= 0 || W <= 0 || T < 1) return fail("cspn_propagate_transposed: bad arguments");
+    if (premask && !sparse_f32) return fail("cspn_propagate_transposed: premask needs sparse");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int blend = premask ? CSPN_BLEND_PREMASK : CSPN_BLEND_NONE;
+#define TRANSPOSED(KV, WTT) \
+    return propagate_typed<KV, WTT, float>(w, g_T, sparse_f32, nullptr, history, nullptr, B, H, W, T, blend, plan, st, 2, 0, 0, \
+                                           nullptr, nullptr, 0, nullptr, W_valid)
+    if (w_dtype == CSPN_F32) {
+        if (K == 3) TRANSPOSED(3, float);
+        if (K == 5) TRANSPOSED(5, float);
+        if (K == 7) TRANSPOSED(7, float);
+    } else if (w_dtype == CSPN_F16) {
+        if (K == 3) TRANSPOSED(3, __half);
+        if (K == 5) TRANSPOSED(5, __half);
+        if (K == 7) TRANSPOSED(7, __half);
+    }
+#undef TRANSPOSED
+    return fail("cspn_propagate_transposed: unsupported K=%d / w_dtype=%d", K, w_dtype);
 }
 
 int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, void* w8_out, const void* d0,

@@ -44,13 +44,29 @@ def set_event_log(log):
     _EVENT_LOG = log
 
 
+_RESOLVED = {}       # (K,B,H,W,T,history,plan items) -> resolved plan dict (cspn_plan_resolve is pure)
+
+
 def resolve_plan(K, B, H, W, T, keep_history=False, plan=None):
-    """The plan the engine will actually use (dict), via cspn_plan_resolve."""
+    """The plan the engine will actually use (dict), via cspn_plan_resolve (memoised: it is a pure function)."""
+    eff = _DEFAULT_PLANS.get(int(K)) if plan is None else plan
+    key = None
+    if eff is None or isinstance(eff, dict):
+        key = (int(K), int(B), int(H), int(W), int(T), bool(keep_history),
+               None if eff is None else tuple(sorted(eff.items())))
+        hit = _RESOLVED.get(key)
+        if hit is not None:
+            return dict(hit)
     out = cspn_plan()
     ok = _lib.lib().cspn_plan_resolve(int(K), int(B), int(H), int(W), int(T), int(bool(keep_history)),
                                       _plan_ptr(K, plan), ctypes.byref(out))
     _lib.check(ok, "cspn_plan_resolve")
-    return {name: int(getattr(out, name)) for name, _ in cspn_plan._fields_}
+    res = {name: int(getattr(out, name)) for name, _ in cspn_plan._fields_}
+    if key is not None:
+        if len(_RESOLVED) > 4096:
+            _RESOLVED.clear()
+        _RESOLVED[key] = dict(res)
+    return res
 
 
 _FROM_GUIDANCE = True    # see set_from_guidance
@@ -311,6 +327,8 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None, valid_w
 
 
 _FROM_GUIDANCE_INSTANCES = ((1, 256), (2, 256), (1, 512), (2, 512), (1, 1024), (2, 1024))
+_TRANSPOSED_INSTANCES = {3: ((1, 256), (2, 256), (1, 512), (2, 512), (1, 1024), (2, 1024)),
+                         5: ((1, 256), (1, 512)), 7: ((1, 256),)}
 _SCORED_INSTANCES = {3: ((1, 256), (1, 512), (1, 1024), (2, 512)), 5: ((1, 256), (1, 512))}
 
 
@@ -439,13 +457,25 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
     ghist[0].copy_(grad_out.reshape(B, H, W))
     if T > 0:
         sp32 = None if sparse is None else sparse.float()
-        wT = transpose_weights(w, K, H, W)
-        with _device_guard(dev):
-            ok = _lib.lib().cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
-                                           CSPN_F32, B, H, W, int(valid_w), int(K), T,
-                                           BLEND_PREMASK if sparse is not None else BLEND_NONE,
-                                           _plan_ptr(K, plan), _stream(dev))
-        _lib.check(ok, "cspn_propagate(backward)")
+        L = _lib.lib()
+        p = None
+        if W % 4 == 0 and w.data_ptr() % 16 == 0 and (sp32 is None or sp32.data_ptr() % 16 == 0):
+            p = resolve_plan(K, B, H, W, T, True, plan)
+        if p is not None and not p["force_scalar"] and (p["quads_per_thread"], p["threads"]) in _TRANSPOSED_INSTANCES[K]:
+            # transposed recurrence straight on the forward tap volume (no transposed copy)
+            with _device_guard(dev):
+                ok = L.cspn_propagate_transposed(_p(w), _dt(w), _p(ghist[0]), _p(sp32), _p(ghist[1]), B, H, W,
+                                                 int(valid_w), int(K), T, int(sparse is not None),
+                                                 _plan_ptr(K, plan), _stream(dev))
+            _lib.check(ok, "cspn_propagate_transposed")
+        else:
+            wT = transpose_weights(w, K, H, W)
+            with _device_guard(dev):
+                ok = L.cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
+                                      CSPN_F32, B, H, W, int(valid_w), int(K), T,
+                                      BLEND_PREMASK if sparse is not None else BLEND_NONE,
+                                      _plan_ptr(K, plan), _stream(dev))
+            _lib.check(ok, "cspn_propagate(backward)")
     return ghist
 
 

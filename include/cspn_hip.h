@@ -134,6 +134,15 @@ int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long g_batc
 
 /* ---- backward ---------------------------------------------------------------------------------- */
 
+/* The backward recurrence  G_t = stencil^T((1-m) G_{t+1}),  G_T = dL/dout,  on the FORWARD tap volume: every launch
+ * reads tap j of the transposed stencil as w[NT-1-j][p+off_j] (aligned quads + lane shifts), so no transposed
+ * copy of the weights is made.  g_T [B,H,W] f32; history [T,B,H,W] f32 receives G_{T-1}..G_0; sparse_f32 (with
+ * premask != 0) is the sparse depth as f32.  Vector path only (W % 4 == 0, 16-byte aligned; returns 0 otherwise:
+ * use cspn_transpose_weights + cspn_propagate(…, CSPN_BLEND_PREMASK)). */
+int cspn_propagate_transposed(const void* w, int w_dtype, const float* g_T, const float* sparse_f32, float* history,
+                              int B, int H, int W, int W_valid, int K, int T, int premask, const cspn_plan* plan,
+                              cspn_stream_t stream);
+
 /* wT[b][j][q] = w[b][NT-1-j][q+off_j] (0 outside): weights of the transposed stencil, so that the
  * backward recurrence G_t = stencilT((1-m) G_{t+1}) runs through cspn_propagate(…, CSPN_BLEND_PREMASK). */
 int cspn_transpose_weights(const void* w, void* wT, int w_dtype, int B, int H, int W, int K,
