@@ -512,34 +512,54 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
 //     workgroup can own, evened out over the image; the (n, height) pair with the fewest total
 //     weight-region pixels (tiles x (tile + halo)) wins, wider tile on ties.
 void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan* p) {
-    (void)B; (void)keep_history;
+    (void)keep_history;
     const int R = K / 2;
     p->force_scalar = 0;
-    p->threads = (K == 3) ? 1024 : 256;
     p->quads_per_thread = 1;
-    int S = (K == 3) ? 8 : (K == 5 ? 3 : 2);
+    p->tile_w = 0;
+    p->tile_h = 0;
+    int S0 = (K == 3) ? 8 : (K == 5 ? 3 : 2);
     if (T < 1) T = 1;
-    if (S > T) S = T;
-    S = ceil_div(T, ceil_div(T, S));                 // balance the launches (T=24, S0=8 -> 3 x 8)
-    for (;; --S) {                                   // shrink S until some tiling fits the workgroup
-        const int hyw = (S - 1) * R, hxw = round_up4(hyw);
-        long best_cost = -1;
-        for (int n = 1; n <= 64; ++n) {
-            const int tw = round_up4(ceil_div(W, n));
-            if (n > 1 && tw < 16) break;
-            const int wq = (tw + 2 * hxw) / 4;
-            if (wq > p->threads) continue;
-            int th = p->quads_per_thread * (p->threads / wq) - 2 * hyw;
-            if (th > H) th = H;
-            if (th < 1 || (th < 8 && th < H)) continue;
-            th = ceil_div(H, ceil_div(H, th));       // even out the tile rows
-            const long cost = (long)ceil_div(W, tw) * ceil_div(H, th) * (4L * wq) * (th + 2 * hyw);
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; p->tile_w = tw; p->tile_h = th; }
+    if (S0 > T) S0 = T;
+    S0 = ceil_div(T, ceil_div(T, S0));               // balance the launches (T=24, S0=8 -> 3 x 8)
+    // Largest workgroup first (least halo); small batches step down to 512 threads when the launch would leave
+    // most CUs without a tile (B=3 at 304x228 with 1024-thread tiles occupies 90 of the 256 CUs).  Going further
+    // down (256 threads) costs more in halo work than it gains in occupancy (plan sweeps at B=1..3).
+    const int thread_opts[3] = {(K == 3) ? 1024 : 256, (K == 3) ? 512 : 0, 0};
+    for (int ti = 0; ti < 3; ++ti) {
+        const int threads = thread_opts[ti];
+        if (!threads) break;
+        int S = S0, tw_best = 0, th_best = 0;
+        long tiles_best = 0;
+        for (;; --S) {                               // shrink S until some tiling fits the workgroup
+            const int hyw = (S - 1) * R, hxw = round_up4(hyw);
+            long best_cost = -1;
+            for (int n = 1; n <= 64; ++n) {
+                const int tw = round_up4(ceil_div(W, n));
+                if (n > 1 && tw < 16) break;
+                const int wq = (tw + 2 * hxw) / 4;
+                if (wq > threads) continue;
+                int th = p->quads_per_thread * (threads / wq) - 2 * hyw;
+                if (th > H) th = H;
+                if (th < 1 || (th < 8 && th < H)) continue;
+                th = ceil_div(H, ceil_div(H, th));   // even out the tile rows
+                const long tiles = (long)ceil_div(W, tw) * ceil_div(H, th);
+                const long cost = tiles * (4L * wq) * (th + 2 * hyw);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; tw_best = tw; th_best = th; tiles_best = tiles; }
+            }
+            if (best_cost >= 0 || S == 1) break;
         }
-        if (best_cost >= 0 || S == 1) break;
+        if (tw_best > 0) {
+            p->threads = threads; p->steps_per_launch = S; p->tile_w = tw_best; p->tile_h = th_best;
+            if ((long)B * tiles_best >= 160) break;  // enough tiles to keep most of the 256 CUs busy
+        }
     }
-    p->steps_per_launch = S;
-    if (p->tile_w <= 0) { p->tile_w = round_up4(W < 64 ? W : 64); p->tile_h = p->threads / (p->tile_w / 4); }
+    if (p->tile_w <= 0) {
+        p->threads = 256;
+        p->steps_per_launch = 1;
+        p->tile_w = round_up4(W < 64 ? W : 64);
+        p->tile_h = p->threads / (p->tile_w / 4);
+    }
 }
 
 void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {

@@ -84,7 +84,7 @@ _TUNED = {}          # autotune cache: problem key -> plan dict
 _NQ_THREADS = {3: ((1, 256), (2, 256), (4, 256), (1, 512), (2, 512), (4, 512), (1, 1024), (2, 1024)),
                5: ((1, 256), (2, 256), (3, 256), (1, 512)),
                7: ((1, 256),)}
-_S_LIST = {3: (1, 3, 4, 5, 6, 8), 5: (1, 2, 3, 4), 7: (1, 2)}
+_S_LIST = {3: (1, 3, 4, 5, 6, 8, 12), 5: (1, 2, 3, 4), 7: (1, 2)}
 
 
 def candidate_plans(K, H, W, T):
