@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 import cspn_monodepth_amd as pkg                      # noqa: E402
 from cspn_monodepth_amd import functional as F        # noqa: E402
 
+if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    pkg._lib.build()                                  # no-op when libcspn_hip.so is current
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 WORKLOADS = {

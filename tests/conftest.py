@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # make sure the in-tree HIP library exists and is current (no-op when it is; hipcc cross-compiles without a GPU)
+    from cspn_monodepth_amd import _lib
+    _lib.build()
 
 
 def golden_names(prefix):
