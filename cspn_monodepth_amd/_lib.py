@@ -37,28 +37,35 @@ class cspn_plan(ctypes.Structure):
                 ("quads_per_thread", ctypes.c_int), ("threads", ctypes.c_int), ("force_scalar", ctypes.c_int)]
 
 
+def _source_digest(flags):
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for path in [os.path.join(CSRC, f) for f in SOURCES] + list(HEADERS):
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU: the translation units are compiled in parallel to
-    csrc/_build/*.o and linked into the in-tree .so (which travels with gpurun snapshots)."""
+    csrc/_build/*.o and linked into the in-tree .so (which travels with gpurun snapshots).  Staleness is decided by
+    a content hash of the sources + flags stored next to the library (file times do not survive every copy)."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
-    deps = srcs + list(HEADERS)
-    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
-        return SO_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # -fno-slp-vectorize: the SLP pass pairs the stencil FMAs into v_pk_fma_f32 and pays for it with ~50 v_mov
     # per step to build operand pairs; scalar v_fma_f32 measured 4 % faster (profiles/).  No fast-math: 0/0 = NaN.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fno-slp-vectorize"] + \
         os.environ.get("CSPN_HIPCC_FLAGS", "").split() + ["-I", INCLUDE]
+    digest = _source_digest(flags[:-2])
+    stamp = SO_PATH + ".hash"
+    if not force and os.path.exists(SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return SO_PATH
     bdir = os.path.join(CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
-                and all(os.path.getmtime(obj) >= os.path.getmtime(h) for h in HEADERS)
-                and not os.environ.get("CSPN_HIPCC_FLAGS")):
-            return obj
         cmd = [hipcc] + flags + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -72,6 +79,8 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(SO_PATH + ".tmp", SO_PATH)
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
     return SO_PATH
 
 
