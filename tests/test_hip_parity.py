@@ -489,3 +489,29 @@ def test_any_width_row_padding_is_exact(W, c_oracle):
         wx, wgd = orc.pac_backward(x, gd, None, cot, 4, np.float64)
         assert np.abs(xt.grad.cpu().numpy() - wx).max() <= 5e-5 * max(1.0, np.abs(wx).max())
         assert np.abs(gdt.grad.cpu().numpy() - wgd).max() <= 5e-4 * max(1.0, np.abs(wgd).max())
+
+
+def test_api_edge_cases(c_oracle):
+    """prop_time = 0 (identity), non-default device index handling, dtype / shape validation errors."""
+    g, d, s = c_oracle.synthetic_inputs(91, 2, 12, 16, 12, 20)
+    with torch.no_grad():
+        out = pkg.CSPN_new.AffinityPropagate(0, 3)(dev(g), dev(d), dev(s))
+    assert torch.equal(out, dev(d))                               # the reference returns blur_depth unchanged
+    gt, dt = dev(g).requires_grad_(True), dev(d).requires_grad_(True)
+    out = pkg.CSPN_new.AffinityPropagate(1, 3)(gt, dt)
+    out.sum().backward()
+    assert torch.isfinite(gt.grad).all() and torch.isfinite(dt.grad).all()
+    m = pkg.CSPN_new.AffinityPropagate(3, 3)
+    with pytest.raises(TypeError):
+        m(dev(g).half(), dev(d))                                  # mixed dtypes
+    with pytest.raises(TypeError):
+        m(dev(g).to(torch.bfloat16), dev(d).to(torch.bfloat16))   # unsupported dtype
+    with pytest.raises(ValueError):
+        m(dev(g)[:, :7], dev(d))                                  # fewer than 8 guidance channels
+    with pytest.raises(ValueError):
+        m(dev(g), dev(d)[:, :, :-1])                              # shape mismatch
+    with pytest.raises(ValueError):
+        pkg.CSPN_ours.AffinityPropagate(3)(dev(d), dev(g)[:, :10])   # 10 channels is not K*K-1
+    sp = dev(s).requires_grad_(True)                              # sparse depth gets no gradient (sign())
+    pkg.CSPN_new.AffinityPropagate(2, 3)(gt, dt, sp).sum().backward()
+    assert sp.grad is None
