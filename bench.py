@@ -75,7 +75,7 @@ def make_inputs(wl, B, device, seed, sparse):
 def cpu_baseline(wl, budget_s=16.0):
     """The reference's CPU op mix (oracle/ref_plumbing_torch.py, a port validated bit-identical to the imported
     reference) on this box's host cores, on a bounded sample of the same workload: single frames and a
-    4-frame batch of the workload's shape, at up to three thread counts (8/16/32, capped by the core count;
+    4-frame batch of the workload's shape, at up to four thread counts (1/8/16/32, capped by the core count;
     256 threads take >60 s per frame) (oneDNN's 5-D conv path scales badly with both
     batch and threads); the best rate is reported."""
     from oracle import ref_plumbing_torch as plumb
@@ -95,7 +95,7 @@ def cpu_baseline(wl, budget_s=16.0):
     tried = []
     t_begin = time.perf_counter()
     with torch.no_grad():
-        for threads in sorted({min(cores, 8), min(cores, 16), min(cores, 32)}):
+        for threads in sorted({1, min(cores, 8), min(cores, 16), min(cores, 32)}):
             torch.set_num_threads(threads)
             for b in (1, 4):
                 if time.perf_counter() - t_begin > budget_s:
@@ -112,7 +112,17 @@ def cpu_baseline(wl, budget_s=16.0):
                 tried.append({"threads": threads, "batch": b, "maps_per_s": rate, "reps": len(times)})
                 if best is None or rate > best[0]:
                     best = (rate, threads, b, len(times))
-    out = {"value": best[0], "unit": "depth-maps/s", "cores": best[1], "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    one = [t for t in tried if t["threads"] == 1]
+    out = {"value": best[0], "unit": "depth-maps/s", "cores": best[1], "kind": "port", "host_cores": cores,
+           "cpu_model": model, "single_thread_value": max(t["maps_per_s"] for t in one) if one else None,
            "sample": "%d forward(s) of %d frame(s) %dx%d, T=%d (median, after warm-up) with %d of %d host threads; "
                      "PyTorch %s CPU op-mix port of the reference (pad/cat/conv3d-ones/div); legs tried: %s" % (
                          best[3], best[2], W, H, T, best[1], cores, torch.__version__, json.dumps(tried))}
