@@ -86,3 +86,28 @@ def test_random_gradient_cases(seed, c_oracle):
         sg, sd = max(1.0, float(np.abs(wg).max())), max(1.0, float(np.abs(wd).max()))
         assert float(np.abs(gt.grad.cpu().numpy() - wg).max()) <= 1e-3 * sg, (B, H, W, T, sparse, plan)
         assert float(np.abs(dt.grad.cpu().numpy() - wd).max()) <= 1e-4 * sd, (B, H, W, T, sparse, plan)
+
+
+def test_special_values_in_depth(c_oracle):
+    """inf / nan / huge / tiny depths: non-finite patterns must spread exactly as in the reference arithmetic
+    (0 * inf = nan, inf - inf = nan, ...), also under temporal blocking and from-guidance weights."""
+    rng = np.random.default_rng(5)
+    B, H, W, T = 2, 40, 56, 7
+    g, d, s = c_oracle.synthetic_inputs(77, B, H, W, 12, 60)
+    flat = d.reshape(-1)
+    idx = rng.choice(flat.size, 12, replace=False)
+    # (values within 8x of FLT_MAX are left out: the reference overflows in its un-normalised sum  sum_k A_k d_k  where
+    #  the engine, which multiplies by pre-normalised weights <= 1, does not — DESIGN.md §1)
+    flat[idx] = np.array([np.inf, -np.inf, np.nan, 1e36, -1e36, 1e-38, 1e-45, 0.0, np.inf, np.nan, 1e30, -1e30], np.float32)
+    g[0, 3, 5, 7] = 0.0
+    g[1, :, 20, 30] = 0.0
+    for sp in (None, s):
+        want = c_oracle.cspn3_forward(g, d, sp, T)
+        for plan in (None, dict(steps_per_launch=1, tile_w=32, tile_h=32, quads_per_thread=1, threads=256),
+                     dict(steps_per_launch=3, tile_w=24, tile_h=26, quads_per_thread=2, threads=256)):
+            with torch.no_grad():
+                out = pkg.CSPN_new.AffinityPropagate(T, 3, plan=plan)(dev(g), dev(d), dev(sp)).cpu().numpy()
+            assert np.array_equal(np.isnan(out), np.isnan(want)), plan
+            assert np.array_equal(np.isposinf(out), np.isposinf(want)) and np.array_equal(np.isneginf(out), np.isneginf(want))
+            fin = np.isfinite(want)
+            assert np.allclose(out[fin], want[fin], rtol=1e-5, atol=1e-30)
