@@ -166,6 +166,18 @@ __device__ __forceinline__ void load_taps_quad(const __half* img, size_t p, size
         out[2 * jp + 1][0] = c.x; out[2 * jp + 1][1] = c.y; out[2 * jp + 1][2] = d.x; out[2 * jp + 1][3] = d.y;
     }
 }
+// acc + w * x with w = element e of tap (2i + odd) taken straight from a packed pair register set (see the f16
+// tap-volume layout: words x,y hold the even tap's pixels (0,1),(2,3), words z,w the odd tap's).  One
+// v_fma_mix_f32 (f16 source selected by op_sel) — written as asm because, given C++ conversions, the optimiser
+// hoists all of them out of the step loop and materialises the weights as fp32 again (197 instead of ~110 VGPRs).
+__device__ __forceinline__ float fma_packed_tap(const uint4& r, int odd, int e, float x, float acc) {
+    const unsigned w = odd ? ((e >> 1) ? r.w : r.z) : ((e >> 1) ? r.y : r.x);
+    float out;
+    if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
+    return out;
+}
+
 // the matching quad stores
 template <int NT>
 __device__ __forceinline__ void store_taps_quad(float* img, size_t p, size_t HW, const float (&v)[NT][4]) {

@@ -89,7 +89,12 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     const bool fix_right = (sx == wq - 1) || (lane == 63);   // right neighbour quad is not lane+1's
 
     // ---- 1. issue the weight stream first (independent of LDS): NQ x NT 16-byte loads -----------
-    float wreg[NQ][NT][4];
+    // f16 tap volumes streamed as prepared weights stay PACKED in registers (one 16-byte load = uint4 = taps 2i, 2i+1
+    // of the quad, two halfs per VGPR) and feed v_fma_mix_f32 directly: half the weight registers of the fp32
+    // form (higher occupancy / more bytes in flight per wave) and no conversion instructions.
+    constexpr bool PACKED = std::is_same<WT, __half>::value && WSRC == 0;
+    float wreg[PACKED ? 1 : NQ][PACKED ? 1 : NT][4];
+    uint4 wpk[PACKED ? NQ : 1][PACKED ? NT / 2 : 1];
     unsigned in_img = 0, interior = 0;
     // Blend operands of the owned quads, om = 1 - m and md0 = m * d0 (m = sign(sparse); both products are exact),
     // are parked in two private LDS planes instead of 8 VGPRs per quad: each thread only ever touches its
@@ -105,7 +110,15 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         const size_t off = (size_t)(ok ? y : 0) * W + (ok ? xq : 0);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (WSRC == 0) {
-            load_taps_quad<NT>(wg, off, HW, ok, wreg[i]);
+            if constexpr (PACKED) {
+                const size_t pair_stride = 2 * Taps<__half>::hw4(HW);
+#pragma unroll
+                for (int jp = 0; jp < NT / 2; ++jp)
+                    wpk[i][jp] = ok ? *reinterpret_cast<const uint4*>(wg + (size_t)jp * pair_stride + 2 * off)
+                                    : make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                load_taps_quad<NT>(wg, off, HW, ok, wreg[i]);
+            }
         } else if constexpr (WSRC == 2) {
             // Transposed stencil (backward recurrence): tap j = w_{NT-1-j}[p + off_j], read straight from the
             // forward tap volume — one aligned quad of plane NT-1-j at row y+dy, shifted by dx columns with the
@@ -353,7 +366,10 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                             const int j = lin < (K * K) / 2 ? lin : lin - 1;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                u[e] = fmaf(wreg[i][j][e], win[i + dy + R][e + dx + R], u[e]);
+                                if constexpr (PACKED)
+                                    u[e] = fma_packed_tap(wpk[i][j >> 1], j & 1, e, win[i + dy + R][e + dx + R], u[e]);
+                                else
+                                    u[e] = fmaf(wreg[i][j][e], win[i + dy + R][e + dx + R], u[e]);
                         }
                     float keep[4];   // value carried to the next step through LDS
                     float om[4] = {1.f, 1.f, 1.f, 1.f}, md[4] = {0.f, 0.f, 0.f, 0.f};
