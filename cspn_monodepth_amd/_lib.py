@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
@@ -29,12 +29,17 @@ EXPORTS = (
     "cspn_transpose_weights",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
+    "cspn_pac_out_size", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col",
 )
 
 
 class cspn_plan(ctypes.Structure):
     _fields_ = [("steps_per_launch", ctypes.c_int), ("tile_w", ctypes.c_int), ("tile_h", ctypes.c_int),
                 ("quads_per_thread", ctypes.c_int), ("threads", ctypes.c_int), ("force_scalar", ctypes.c_int)]
+
+
+class cspn_conv_geometry(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "oph", "opw", "transposed")]
 
 
 def _source_digest(flags):
@@ -112,6 +117,12 @@ def _declare(lib):
     lib.cspn3_backward_tail.argtypes = [vp, vp, vp, vp, vp, cl, cl, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_pac_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, ci, vp]
+    geom = ctypes.POINTER(cspn_conv_geometry)
+    lib.cspn_pac_out_size.argtypes = [ci, ci, geom, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.cspn_pac_conv2d.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
+    lib.cspn_pac_conv2d_grad_input.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
+    lib.cspn_pac_conv2d_grad_kernel.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
+    lib.cspn_pac_nd2col.argtypes = [vp, vp, ci, ci, ci, ci, ci, geom, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes"):

@@ -1,0 +1,145 @@
+"""Pixel-adaptive convolution on the HIP engine — the interface of the reference's network/libs/base/pac.py.
+
+    from cspn_monodepth_amd.base.pac import conv2d            # was: from network.libs.base.pac import conv2d
+
+``conv2d(input, kernel, kernel_size, stride=1, padding=0, dilation=1, native_impl=False)`` (pac.py:124-144),
+``Conv2dFn`` (pac.py:73-121) and ``nd2col`` (pac.py:35-70) keep the reference's names, argument order, shapes and
+its ``ValueError('Incompatible input and kernel sizes.')``.  Every call runs libcspn_hip.so (cspn_pac_conv2d,
+cspn_pac_conv2d_grad_input / _grad_kernel, cspn_pac_nd2col in include/cspn_hip.h); there is no unfold, no im2col
+buffer ([B, C*K*K, L] in the reference) and no CPU path.
+
+Differences, all documented in DESIGN.md §9:
+  * ``native_impl`` selects between two formulations of the same sum in the reference (identical outputs, golden
+    manifest ``branches_max_abs`` = 0); here both values run the one HIP kernel.
+  * ``Conv2dFn.backward`` works (the reference's needs the THNN backend removed in torch 1.0).
+  * ``nd2col(transposed=True)`` accepts any channel count (the reference's 1x1 ones-kernel trick only C = 1);
+    ``use_pyinn_if_possible`` is accepted and ignored (PyINN is a CUDA-only dependency).
+  * fp16 tensors accumulate in fp32 and round once (the reference multiplies and sums in half).
+"""
+import ctypes
+from numbers import Number
+
+import torch
+from torch.autograd.function import Function, once_differentiable
+
+from .. import _lib
+from ..functional import _device_guard, _dt, _p, _require_device, _stream
+
+__all__ = ["conv2d", "Conv2dFn", "nd2col", "output_size"]
+
+
+def _pair(v):
+    if isinstance(v, Number):
+        return (int(v), int(v))
+    v = tuple(int(x) for x in v)
+    if len(v) != 2:
+        raise ValueError("expected a number or a pair, got %r" % (v,))
+    return v
+
+
+def _geometry(kernel_size, stride, padding, dilation, output_padding=0, transposed=False):
+    k, s, p, d, op = (_pair(x) for x in (kernel_size, stride, padding, dilation, output_padding))
+    return _lib.cspn_conv_geometry(k[0], k[1], s[0], s[1], p[0], p[1], d[0], d[1], op[0], op[1], int(bool(transposed)))
+
+
+def output_size(in_size, kernel_size, stride=1, padding=0, dilation=1, output_padding=0, transposed=False):
+    """(Ho, Wo) of the op for an (H, W) input (pac.py:41-42, :61-62, :132-133)."""
+    g = _geometry(kernel_size, stride, padding, dilation, output_padding, transposed)
+    ho, wo = ctypes.c_int(0), ctypes.c_int(0)
+    ok = _lib.lib().cspn_pac_out_size(int(in_size[0]), int(in_size[1]), ctypes.byref(g), ctypes.byref(ho), ctypes.byref(wo))
+    _lib.check(ok, "cspn_pac_out_size")
+    return ho.value, wo.value
+
+
+def _check_io(input, kernel, g):
+    if input.dim() != 4:
+        raise ValueError("input must be [B,C,H,W], got %s" % (tuple(input.shape),))
+    if kernel.dim() != 6:
+        raise ValueError("kernel must be [B,1|C,kh,kw,Ho,Wo], got %s" % (tuple(kernel.shape),))
+    B, C, H, W = input.shape
+    if kernel.size(1) > 1 and kernel.size(1) != C:                       # pac.py:77-78
+        raise ValueError("Incompatible input and kernel sizes.")
+    if kernel.dtype != input.dtype:
+        raise TypeError("input and kernel must have one dtype, got %s and %s" % (input.dtype, kernel.dtype))
+    Ho, Wo = output_size((H, W), (g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw))
+    if tuple(kernel.shape) != (B, kernel.size(1), g.kh, g.kw, Ho, Wo):
+        raise ValueError("kernel of shape %s does not match input %s under this geometry (expected [%d,%d,%d,%d,%d,%d])"
+                         % (tuple(kernel.shape), tuple(input.shape), B, kernel.size(1), g.kh, g.kw, Ho, Wo))
+    return B, C, H, W, Ho, Wo
+
+
+def _forward(input, kernel, g):
+    B, C, H, W, Ho, Wo = _check_io(input, kernel, g)          # shape errors first, as the reference (pac.py:77-78)
+    dev = _require_device(input, kernel)
+    x, k = input.contiguous(), kernel.contiguous()
+    out = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=dev)
+    with _device_guard(dev):
+        ok = _lib.lib().cspn_pac_conv2d(_p(x), _p(k), _p(out), _dt(x), B, C, k.size(1), H, W, ctypes.byref(g), _stream(dev))
+    _lib.check(ok, "cspn_pac_conv2d")
+    return out
+
+
+class Conv2dFn(Function):
+    """pac.py:73-121.  Saves input / kernel only where the other one needs a gradient, as the reference does (:85-86)."""
+
+    @staticmethod
+    def forward(ctx, input, kernel, kernel_size, stride=1, padding=0, dilation=1):
+        g = _geometry(kernel_size, stride, padding, dilation)
+        out = _forward(input, kernel, g)
+        ctx.geom = g
+        ctx.input_shape = tuple(input.shape)
+        ctx.kernel_ch = kernel.size(1)
+        ctx.save_for_backward(input if ctx.needs_input_grad[1] else None,
+                              kernel if ctx.needs_input_grad[0] else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, kernel = ctx.saved_tensors
+        g = ctx.geom
+        B, C, H, W = ctx.input_shape
+        dev = _require_device(grad_output)
+        go = grad_output.contiguous()
+        grad_input = grad_kernel = None
+        L = _lib.lib()
+        with _device_guard(dev):
+            if ctx.needs_input_grad[0]:
+                k = kernel.contiguous()
+                grad_input = torch.empty((B, C, H, W), dtype=go.dtype, device=dev)
+                ok = L.cspn_pac_conv2d_grad_input(_p(go), _p(k), _p(grad_input), _dt(go), B, C, ctx.kernel_ch, H, W,
+                                                  ctypes.byref(g), _stream(dev))
+                _lib.check(ok, "cspn_pac_conv2d_grad_input")
+            if ctx.needs_input_grad[1]:
+                x = input.contiguous()
+                Ho, Wo = go.shape[-2:]
+                grad_kernel = torch.empty((B, ctx.kernel_ch, g.kh, g.kw, Ho, Wo), dtype=go.dtype, device=dev)
+                ok = L.cspn_pac_conv2d_grad_kernel(_p(go), _p(x), _p(grad_kernel), _dt(go), B, C, ctx.kernel_ch, H, W,
+                                                   ctypes.byref(g), _stream(dev))
+                _lib.check(ok, "cspn_pac_conv2d_grad_kernel")
+        return grad_input, grad_kernel, None, None, None, None
+
+
+def conv2d(input, kernel, kernel_size, stride=1, padding=0, dilation=1, native_impl=False):
+    """out[b,c] = sum_ij kernel[b,c|0,i,j] * unfold(input)[b,c,i,j]  (pac.py:124-144).  ``native_impl`` is accepted
+    for signature compatibility; both of the reference's branches are this one kernel here."""
+    if torch.is_grad_enabled() and (input.requires_grad or kernel.requires_grad):
+        return Conv2dFn.apply(input, kernel, kernel_size, stride, padding, dilation)
+    return _forward(input, kernel, _geometry(kernel_size, stride, padding, dilation))
+
+
+def nd2col(input_nd, kernel_size, stride=1, padding=0, output_padding=0, dilation=1, transposed=False,
+           use_pyinn_if_possible=False):
+    """[B,C,H,W] -> [B,C,kh,kw,Ho,Wo] (pac.py:35-70; 2-D only, as F.unfold).  Not differentiable here."""
+    dev = _require_device(input_nd)
+    if input_nd.dim() != 4:
+        raise ValueError("nd2col: only [B,C,H,W] input is supported (as F.unfold), got %s" % (tuple(input_nd.shape),))
+    g = _geometry(kernel_size, stride, padding, dilation, output_padding, transposed)
+    B, C, H, W = input_nd.shape
+    Ho, Wo = output_size((H, W), (g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw), (g.oph, g.opw), transposed)
+    x = input_nd.detach().contiguous()
+    cols = torch.empty((B, C, g.kh, g.kw, Ho, Wo), dtype=x.dtype, device=dev)
+    with _device_guard(dev):
+        ok = _lib.lib().cspn_pac_nd2col(_p(x), _p(cols), _dt(x), B, C, H, W, ctypes.byref(g), _stream(dev))
+    _lib.check(ok, "cspn_pac_nd2col")
+    return cols

@@ -1,0 +1,427 @@
+// pac_conv2d.hip — general pixel-adaptive convolution (network/libs/base/pac.py), SURVEY.md §8 f-3.
+//
+// One step of  out[b,c,y,x] = sum_ij kernel[b,c|0,i,j,y,x] * in0[b,c, y*sh-ph+i*dh, x*sw-pw+j*dw]  for any channel count,
+// stride, padding, dilation, plus its two gradients and nd2col.  HBM-bound streaming work: per output pixel the op
+// reads kh*kw kernel values (once, they are the bulk), C inputs (re-used kh*kw times out of L1/L2) and writes C
+// outputs.  Every thread owns a quad of 4 consecutive output pixels so the kernel planes move as 16-byte accesses;
+// channels are walked CC at a time against the same kernel registers.  The K x K recurrence of CSPN_ours
+// (C = 1, stride 1, "same" padding, T steps) does NOT come through here — cspn_propagate keeps it in LDS.
+#include "cspn_common.hpp"
+
+namespace {
+
+struct ConvArgs {
+    int B, C, CK, H, W, Ho, Wo, WQ;      // WQ = ceil(Wo / 4) output quads per row
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int lead_h, lead_w;                  // transposed nd2col: leading pad (k-1)*d - p on the zero-inserted plane
+    int transposed;
+    int cchunk;                          // channels per blockIdx.y
+    int vec;                             // Wo % 4 == 0 and 16-byte (8 for f16) aligned bases: quad loads/stores
+};
+
+// source index along one axis for output index o and tap t, or -1 where the window sees a zero
+__device__ __forceinline__ int src_plain(int o, int t, int S, int P, int D, int N) {
+    const int v = o * S - P + t * D;
+    return (unsigned)v < (unsigned)N ? v : -1;
+}
+__device__ __forceinline__ int src_transposed(int o, int t, int S, int lead, int D, int N) {
+    int v = o + t * D - lead;                      // position on the zero-inserted plane (pac.py:53-56)
+    if (v < 0 || v % S) return -1;
+    v /= S;
+    return v < N ? v : -1;
+}
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void load_quad(const T* p, int x0, int Wo, float (&v)[4]) {
+    if constexpr (VEC) {
+        const float4 q = ld4(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x0 + e < Wo ? ld1(p + e) : 0.f;
+    }
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void store_quad(T* p, int x0, int Wo, const float (&v)[4]) {
+    if constexpr (VEC) {
+        st4(p, make_float4(v[0], v[1], v[2], v[3]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < Wo) st1(p + e, v[e]);
+    }
+}
+
+constexpr int CC = 4;    // channels accumulated against one set of kernel registers
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, bool VEC, bool SHARED>
+__global__ __launch_bounds__(256) void pac_conv2d_fwd(const T* __restrict__ in, const T* __restrict__ kern,
+                                                      T* __restrict__ out, ConvArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.Ho * a.WQ) return;
+    const int y = q / a.WQ, x0 = (q - y * a.WQ) * 4;
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const size_t opix = (size_t)y * a.Wo + x0;
+    const int ntap = a.kh * a.kw;
+    int xs[4];                                        // x*sw - pw for the four pixels
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xs[e] = (x0 + e) * a.sw - a.pw;
+    for (int c = c_begin; c < c_end; c += CC) {
+        const int nc = min(CC, c_end - c);
+        float acc[CC][4];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
+        const T* inb = in + ((size_t)b * a.C + c) * iplane;
+        for (int i = 0; i < a.kh; ++i) {
+            const int yi = src_plain(y, i, a.sh, a.ph, a.dh, a.H);
+            for (int j = 0; j < a.kw; ++j) {
+                const int tap = i * a.kw + j;
+                int xi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = xs[e] + j * a.dw;
+                    xi[e] = (yi >= 0 && (unsigned)v < (unsigned)a.W) ? v : -1;
+                }
+                float kv[4];
+                if constexpr (SHARED) load_quad<T, VEC>(kern + ((size_t)b * ntap + tap) * oplane + opix, x0, a.Wo, kv);
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) {
+                    if (cc < nc) {
+                        if constexpr (!SHARED)
+                            load_quad<T, VEC>(kern + (((size_t)b * a.C + c + cc) * ntap + tap) * oplane + opix, x0, a.Wo, kv);
+                        const T* row = inb + (size_t)cc * iplane + (size_t)(yi < 0 ? 0 : yi) * a.W;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // a zero of the padding still multiplies the kernel value (0 * inf = NaN, as F.unfold * kernel)
+                            const float v = xi[e] >= 0 ? ld1(row + xi[e]) : 0.f;
+                            acc[cc][e] = fmaf(kv[e], v, acc[cc][e]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+            if (cc < nc) store_quad<T, VEC>(out + ((size_t)b * a.C + c + cc) * oplane + opix, x0, a.Wo, acc[cc]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dkernel
+// thread = (output quad, tap); blockIdx.y = tap.  grad_kernel[b,c|0,i,j,y,x] = (sum_c) g[b,c,y,x] * in0[b,c,...]
+template <typename T, bool VEC, bool SHARED>
+__global__ __launch_bounds__(256) void pac_conv2d_gk(const T* __restrict__ gout, const T* __restrict__ in,
+                                                     T* __restrict__ gk, ConvArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.Ho * a.WQ) return;
+    const int y = q / a.WQ, x0 = (q - y * a.WQ) * 4;
+    const int b = blockIdx.z, tap = blockIdx.y;
+    const int i = tap / a.kw, j = tap - i * a.kw;
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const size_t opix = (size_t)y * a.Wo + x0;
+    const int ntap = a.kh * a.kw;
+    const int yi = src_plain(y, i, a.sh, a.ph, a.dh, a.H);
+    int xi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int v = (x0 + e) * a.sw - a.pw + j * a.dw;
+        xi[e] = (yi >= 0 && (unsigned)v < (unsigned)a.W) ? v : -1;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.C; ++c) {
+        float g[4];
+        load_quad<T, VEC>(gout + ((size_t)b * a.C + c) * oplane + opix, x0, a.Wo, g);
+        const T* row = in + ((size_t)b * a.C + c) * iplane + (size_t)(yi < 0 ? 0 : yi) * a.W;
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = g[e] * (xi[e] >= 0 ? ld1(row + xi[e]) : 0.f);
+        if constexpr (SHARED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += p[e];
+        } else {
+            store_quad<T, VEC>(gk + (((size_t)b * a.C + c) * ntap + tap) * oplane + opix, x0, a.Wo, p);
+        }
+    }
+    if constexpr (SHARED) store_quad<T, VEC>(gk + ((size_t)b * ntap + tap) * oplane + opix, x0, a.Wo, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dinput
+// Gather form of the fold (pac.py:104-113): thread = quad of 4 consecutive INPUT pixels; for every tap the output
+// pixel whose window puts that tap on this input pixel contributes g * kernel.  WQ here counts input quads.
+template <typename T, bool SHARED, bool UNIT_STRIDE>
+__global__ __launch_bounds__(256) void pac_conv2d_gi(const T* __restrict__ gout, const T* __restrict__ kern,
+                                                     T* __restrict__ gin, ConvArgs a, int in_wq, int in_vec) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.H * in_wq) return;
+    const int yy = q / in_wq, x0 = (q - yy * in_wq) * 4;
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const int ntap = a.kh * a.kw;
+    for (int c = c_begin; c < c_end; c += CC) {
+        const int nc = min(CC, c_end - c);
+        float acc[CC][4];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
+        for (int i = 0; i < a.kh; ++i) {
+            int ty = yy + a.ph - i * a.dh;
+            if (ty < 0) continue;
+            if constexpr (!UNIT_STRIDE) {
+                if (ty % a.sh) continue;
+                ty /= a.sh;
+            }
+            if (ty >= a.Ho) continue;
+            for (int j = 0; j < a.kw; ++j) {
+                const int tap = i * a.kw + j;
+                int xo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int tx = x0 + e + a.pw - j * a.dw;
+                    bool ok = tx >= 0 && x0 + e < a.W;
+                    if constexpr (!UNIT_STRIDE) {
+                        ok = ok && (tx % a.sw) == 0;
+                        tx /= a.sw;
+                    }
+                    xo[e] = (ok && tx < a.Wo) ? tx : -1;
+                }
+                const size_t orow = (size_t)ty * a.Wo;
+                float kv[4];
+                if constexpr (SHARED) {
+                    const T* kp = kern + ((size_t)b * ntap + tap) * oplane + orow;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kv[e] = xo[e] >= 0 ? ld1(kp + xo[e]) : 0.f;
+                }
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) {
+                    if (cc < nc) {
+                        if constexpr (!SHARED) {
+                            const T* kp = kern + (((size_t)b * a.C + c + cc) * ntap + tap) * oplane + orow;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) kv[e] = xo[e] >= 0 ? ld1(kp + xo[e]) : 0.f;
+                        }
+                        const T* gp = gout + ((size_t)b * a.C + c + cc) * oplane + orow;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (xo[e] >= 0) acc[cc][e] = fmaf(kv[e], ld1(gp + xo[e]), acc[cc][e]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (cc < nc) {
+                T* dst = gin + ((size_t)b * a.C + c + cc) * iplane + (size_t)yy * a.W + x0;
+                if (in_vec) store_quad<T, true>(dst, x0, a.W, acc[cc]);
+                else store_quad<T, false>(dst, x0, a.W, acc[cc]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ nd2col
+// thread = output quad of one (b*C + c, tap) plane.  blockIdx.y = tap, blockIdx.z = b*C + c.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void pac_nd2col_kernel(const T* __restrict__ in, T* __restrict__ cols, ConvArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.Ho * a.WQ) return;
+    const int y = q / a.WQ, x0 = (q - y * a.WQ) * 4;
+    const int tap = blockIdx.y, bc = blockIdx.z;
+    const int i = tap / a.kw, j = tap - i * a.kw;
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const int yi = a.transposed ? src_transposed(y, i, a.sh, a.lead_h, a.dh, a.H) : src_plain(y, i, a.sh, a.ph, a.dh, a.H);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int xi = a.transposed ? src_transposed(x0 + e, j, a.sw, a.lead_w, a.dw, a.W)
+                                    : src_plain(x0 + e, j, a.sw, a.pw, a.dw, a.W);
+        v[e] = (yi >= 0 && xi >= 0 && x0 + e < a.Wo) ? ld1(in + (size_t)bc * iplane + (size_t)yi * a.W + xi) : 0.f;
+    }
+    store_quad<T, VEC>(cols + ((size_t)bc * (a.kh * a.kw) + tap) * oplane + (size_t)y * a.Wo + x0, x0, a.Wo, v);
+}
+
+// ------------------------------------------------------------------------------------------------ host
+bool out_size(int H, int W, const cspn_conv_geometry& g, int* Ho, int* Wo) {
+    long ho, wo;
+    if (g.transposed) {
+        ho = (long)(H - 1) * g.sh - 2L * g.ph + (long)g.dh * (g.kh - 1) + 1 + g.oph;
+        wo = (long)(W - 1) * g.sw - 2L * g.pw + (long)g.dw * (g.kw - 1) + 1 + g.opw;
+    } else {
+        const long nh = (long)H + 2L * g.ph - (long)g.dh * (g.kh - 1) - 1;
+        const long nw = (long)W + 2L * g.pw - (long)g.dw * (g.kw - 1) - 1;
+        if (nh < 0 || nw < 0) return false;
+        ho = nh / g.sh + 1;
+        wo = nw / g.sw + 1;
+    }
+    if (ho < 1 || wo < 1 || ho > (1L << 30) || wo > (1L << 30)) return false;
+    *Ho = (int)ho;
+    *Wo = (int)wo;
+    return true;
+}
+
+int make_args(const char* who, int dtype, int B, int C, int CK, int H, int W, const cspn_conv_geometry* g,
+              bool allow_transposed, ConvArgs* a) {
+    if (!g) return fail("%s: geom is null", who);
+    if (dtype != CSPN_F32 && dtype != CSPN_F16) return fail("%s: dtype must be CSPN_F32 or CSPN_F16", who);
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail("%s: empty tensor (B=%d C=%d H=%d W=%d)", who, B, C, H, W);
+    if (g->kh < 1 || g->kw < 1 || g->sh < 1 || g->sw < 1 || g->dh < 1 || g->dw < 1 || g->ph < 0 || g->pw < 0 ||
+        g->oph < 0 || g->opw < 0)
+        return fail("%s: bad geometry (k %dx%d, stride %d,%d, pad %d,%d, dilation %d,%d)", who, g->kh, g->kw, g->sh,
+                    g->sw, g->ph, g->pw, g->dh, g->dw);
+    if (g->transposed && !allow_transposed) return fail("%s: transposed geometry is for nd2col only", who);
+    if (!g->transposed && (g->oph || g->opw)) return fail("%s: output_padding needs transposed", who);
+    if (CK != 1 && CK != C) return fail("%s: Incompatible input and kernel sizes (kernel_ch=%d, C=%d)", who, CK, C);
+    if (B > 65535) return fail("%s: B=%d exceeds the grid limit 65535", who, B);
+    if ((long)g->kh * g->kw > 65535) return fail("%s: window %dx%d too large", who, g->kh, g->kw);
+    ConvArgs r{};
+    r.B = B; r.C = C; r.CK = CK; r.H = H; r.W = W;
+    r.kh = g->kh; r.kw = g->kw; r.sh = g->sh; r.sw = g->sw; r.ph = g->ph; r.pw = g->pw; r.dh = g->dh; r.dw = g->dw;
+    r.transposed = g->transposed ? 1 : 0;
+    r.lead_h = (g->kh - 1) * g->dh - g->ph;
+    r.lead_w = (g->kw - 1) * g->dw - g->pw;
+    if (r.transposed && (r.lead_h < 0 || r.lead_w < 0))
+        return fail("%s: transposed geometry with padding > (k-1)*dilation is not defined (negative pad)", who);
+    if (!out_size(H, W, *g, &r.Ho, &r.Wo)) return fail("%s: geometry gives an empty output for input %dx%d", who, H, W);
+    r.WQ = ceil_div(r.Wo, 4);
+    if ((size_t)r.Ho * r.WQ > (size_t)1 << 30) return fail("%s: plane too large", who);
+    *a = r;
+    return 1;
+}
+
+// spread channels over blockIdx.y until the launch has enough workgroups to fill 256 CUs a few times over
+int channel_chunk(int C, size_t spatial_blocks) {
+    const size_t want = 2048;
+    if (spatial_blocks >= want || C <= CC) return C;
+    size_t nchunk = (want + spatial_blocks - 1) / spatial_blocks;
+    const size_t maxchunk = (size_t)ceil_div(C, CC);
+    if (nchunk > maxchunk) nchunk = maxchunk;
+    int per = ceil_div(C, (int)nchunk);
+    per = ceil_div(per, CC) * CC;
+    return per;
+}
+
+bool aligned_for(const void* p, int dtype) {
+    return (reinterpret_cast<uintptr_t>(p) & (dtype == CSPN_F16 ? 7 : 15)) == 0;
+}
+
+template <typename T>
+int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, hipStream_t st) {
+    const int gx = ceil_div(a.Ho * a.WQ, 256);
+    a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
+    const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
+    const T* i = static_cast<const T*>(in);
+    const T* k = static_cast<const T*>(kern);
+    T* o = static_cast<T*>(out);
+    const bool shared = a.CK == 1;
+    if (a.vec && shared) pac_conv2d_fwd<T, true, true><<<grid, block, 0, st>>>(i, k, o, a);
+    else if (a.vec) pac_conv2d_fwd<T, true, false><<<grid, block, 0, st>>>(i, k, o, a);
+    else if (shared) pac_conv2d_fwd<T, false, true><<<grid, block, 0, st>>>(i, k, o, a);
+    else pac_conv2d_fwd<T, false, false><<<grid, block, 0, st>>>(i, k, o, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+template <typename T>
+int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStream_t st) {
+    const dim3 grid(ceil_div(a.Ho * a.WQ, 256), a.kh * a.kw, a.B), block(256);
+    const T* g = static_cast<const T*>(gout);
+    const T* i = static_cast<const T*>(in);
+    T* o = static_cast<T*>(gk);
+    const bool shared = a.CK == 1;
+    if (a.vec && shared) pac_conv2d_gk<T, true, true><<<grid, block, 0, st>>>(g, i, o, a);
+    else if (a.vec) pac_conv2d_gk<T, true, false><<<grid, block, 0, st>>>(g, i, o, a);
+    else if (shared) pac_conv2d_gk<T, false, true><<<grid, block, 0, st>>>(g, i, o, a);
+    else pac_conv2d_gk<T, false, false><<<grid, block, 0, st>>>(g, i, o, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+template <typename T>
+int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int in_vec, hipStream_t st) {
+    const int in_wq = ceil_div(a.W, 4);
+    const int gx = ceil_div(a.H * in_wq, 256);
+    a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
+    const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
+    const T* g = static_cast<const T*>(gout);
+    const T* k = static_cast<const T*>(kern);
+    T* o = static_cast<T*>(gin);
+    const bool shared = a.CK == 1, unit = a.sh == 1 && a.sw == 1;
+    if (shared && unit) pac_conv2d_gi<T, true, true><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    else if (shared) pac_conv2d_gi<T, true, false><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    else if (unit) pac_conv2d_gi<T, false, true><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    else pac_conv2d_gi<T, false, false><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+template <typename T>
+int nd2col_typed(const void* in, void* cols, ConvArgs a, hipStream_t st) {
+    if ((long)a.B * a.C > 65535) return fail("cspn_pac_nd2col: B*C=%ld exceeds the grid limit 65535", (long)a.B * a.C);
+    const dim3 grid(ceil_div(a.Ho * a.WQ, 256), a.kh * a.kw, a.B * a.C), block(256);
+    if (a.vec) pac_nd2col_kernel<T, true><<<grid, block, 0, st>>>(static_cast<const T*>(in), static_cast<T*>(cols), a);
+    else pac_nd2col_kernel<T, false><<<grid, block, 0, st>>>(static_cast<const T*>(in), static_cast<T*>(cols), a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int* Wo) {
+    if (!geom || !Ho || !Wo) return fail("cspn_pac_out_size: null argument");
+    if (H < 1 || W < 1 || geom->kh < 1 || geom->kw < 1 || geom->sh < 1 || geom->sw < 1 || geom->dh < 1 || geom->dw < 1)
+        return fail("cspn_pac_out_size: bad geometry");
+    if (!out_size(H, W, *geom, Ho, Wo)) return fail("cspn_pac_out_size: empty output");
+    return 1;
+}
+
+int cspn_pac_conv2d(const void* input, const void* kernel, void* out, int dtype, int B, int C, int kernel_ch,
+                    int H, int W, const cspn_conv_geometry* geom, cspn_stream_t stream) {
+    ConvArgs a;
+    if (!make_args("cspn_pac_conv2d", dtype, B, C, kernel_ch, H, W, geom, false, &a)) return 0;
+    if (!input || !kernel || !out) return fail("cspn_pac_conv2d: null pointer");
+    a.vec = a.Wo % 4 == 0 && aligned_for(kernel, dtype) && aligned_for(out, dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == CSPN_F16 ? conv_forward_typed<__half>(input, kernel, out, a, st)
+                             : conv_forward_typed<float>(input, kernel, out, a, st);
+}
+
+int cspn_pac_conv2d_grad_kernel(const void* grad_out, const void* input, void* grad_kernel, int dtype, int B, int C,
+                                int kernel_ch, int H, int W, const cspn_conv_geometry* geom, cspn_stream_t stream) {
+    ConvArgs a;
+    if (!make_args("cspn_pac_conv2d_grad_kernel", dtype, B, C, kernel_ch, H, W, geom, false, &a)) return 0;
+    if (!grad_out || !input || !grad_kernel) return fail("cspn_pac_conv2d_grad_kernel: null pointer");
+    a.vec = a.Wo % 4 == 0 && aligned_for(grad_out, dtype) && aligned_for(grad_kernel, dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == CSPN_F16 ? conv_gk_typed<__half>(grad_out, input, grad_kernel, a, st)
+                             : conv_gk_typed<float>(grad_out, input, grad_kernel, a, st);
+}
+
+int cspn_pac_conv2d_grad_input(const void* grad_out, const void* kernel, void* grad_input, int dtype, int B, int C,
+                               int kernel_ch, int H, int W, const cspn_conv_geometry* geom, cspn_stream_t stream) {
+    ConvArgs a;
+    if (!make_args("cspn_pac_conv2d_grad_input", dtype, B, C, kernel_ch, H, W, geom, false, &a)) return 0;
+    if (!grad_out || !kernel || !grad_input) return fail("cspn_pac_conv2d_grad_input: null pointer");
+    const int in_vec = W % 4 == 0 && aligned_for(grad_input, dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == CSPN_F16 ? conv_gi_typed<__half>(grad_out, kernel, grad_input, a, in_vec, st)
+                             : conv_gi_typed<float>(grad_out, kernel, grad_input, a, in_vec, st);
+}
+
+int cspn_pac_nd2col(const void* input, void* cols, int dtype, int B, int C, int H, int W,
+                    const cspn_conv_geometry* geom, cspn_stream_t stream) {
+    ConvArgs a;
+    if (!make_args("cspn_pac_nd2col", dtype, B, C, 1, H, W, geom, true, &a)) return 0;
+    if (!input || !cols) return fail("cspn_pac_nd2col: null pointer");
+    a.vec = a.Wo % 4 == 0 && aligned_for(cols, dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == CSPN_F16 ? nd2col_typed<__half>(input, cols, a, st) : nd2col_typed<float>(input, cols, a, st);
+}
+
+}  // extern "C"

@@ -190,6 +190,40 @@ int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* ghist
 int cspn_metrics_accumulate(const void* pred, const void* target, int dtype, size_t n,
                             double* acc, int nslots, cspn_stream_t stream);
 
+/* ---- general pixel-adaptive convolution (network/libs/base/pac.py) ------- *
+ * The single-step, multi-channel, strided / dilated form of the op the K x K recurrence iterates.  All tensors
+ * are contiguous and of one dtype (CSPN_F32 / CSPN_F16, fp32 accumulation):
+ *   input  [B, C, H, W]
+ *   kernel [B, kernel_ch, kh, kw, Ho, Wo], kernel_ch = 1 (shared by all channels) or C
+ *   out    [B, C, Ho, Wo],  Ho = (H + 2 ph - dh (kh-1) - 1) / sh + 1 (same for Wo)             pac.py:61-62
+ * out[b,c,y,x] = sum_ij kernel[b,c|0,i,j,y,x] * in0[b,c, y sh - ph + i dh, x sw - pw + j dw], in0 = zero-extended
+ * input (pac.py:89-92).  Plain layouts here: this op does NOT use the engine's interleaved fp16 tap volume. */
+typedef struct cspn_conv_geometry {
+    int kh, kw;               /* window                    (kernel_size, pac.py:125) */
+    int sh, sw;               /* stride                    (pac.py:126) */
+    int ph, pw;               /* zero padding              (pac.py:127) */
+    int dh, dw;               /* dilation                  (pac.py:128) */
+    int oph, opw;             /* output_padding            (nd2col transposed only, pac.py:56) */
+    int transposed;           /* nd2col only: fractional stride (pac.py:51-58); must be 0 for conv2d */
+} cspn_conv_geometry;
+
+/* Output extent for an input extent under `geom` (pac.py:41-42); writes Ho, Wo; 0 if the result is empty/invalid. */
+int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int* Wo);
+
+/* Conv2dFn.forward (pac.py:75-94) == the native_impl branch (pac.py:130-140). */
+int cspn_pac_conv2d(const void* input, const void* kernel, void* out, int dtype, int B, int C, int kernel_ch,
+                    int H, int W, const cspn_conv_geometry* geom, cspn_stream_t stream);
+/* Conv2dFn.backward (pac.py:98-121): grad_input [B,C,H,W] = fold(grad_out (x) kernel) (:104-113) — computed as a
+ * gather per input pixel, no atomics, deterministic; grad_kernel [B,kernel_ch,kh,kw,Ho,Wo] =
+ * grad_out * unfold(input), summed over channels when kernel_ch == 1 (:115-119). */
+int cspn_pac_conv2d_grad_input(const void* grad_out, const void* kernel, void* grad_input, int dtype, int B, int C,
+                               int kernel_ch, int H, int W, const cspn_conv_geometry* geom, cspn_stream_t stream);
+int cspn_pac_conv2d_grad_kernel(const void* grad_out, const void* input, void* grad_kernel, int dtype, int B, int C,
+                                int kernel_ch, int H, int W, const cspn_conv_geometry* geom, cspn_stream_t stream);
+/* nd2col (pac.py:35-70), 2-D: cols [B, C, kh, kw, Ho, Wo]; geom->transposed selects the zero-insertion form. */
+int cspn_pac_nd2col(const void* input, void* cols, int dtype, int B, int C, int H, int W,
+                    const cspn_conv_geometry* geom, cspn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+"""GPU parity tests of the general pixel-adaptive conv op (cspn_pac_conv2d & co through the C ABI, host mirror
+cspn_monodepth_amd.base.pac) against the golden vectors captured from the reference's pac.py and against the numpy
+oracle on seeded random geometries.  Tolerance: 1e-5 of the tensor's scale for fp32 (a sum of <= 49 products)."""
+import numpy as np
+import pytest
+import torch
+
+import cspn_monodepth_amd as pkg
+from cspn_monodepth_amd import functional as F
+from cspn_monodepth_amd.base import pac
+from conftest import golden_names, load_golden
+from oracle import cspn_oracle as orc
+from oracle import pac_oracle as porc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+CONV_CASES = [n for n in golden_names("g9_") if "nd2col" not in n and n != "g9_fp16"]
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def geom_of(z):
+    kh, kw, sh, sw, ph, pw, dh, dw = (int(v) for v in z["geom"][:8])
+    return (kh, kw), (sh, sw), (ph, pw), (dh, dw)
+
+
+def nmax(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def run_all(x, kern, cot, k, s, p, d, dtype=torch.float32):
+    xt = dev(x, dtype).requires_grad_(True)
+    kt = dev(kern, dtype).requires_grad_(True)
+    out = pac.conv2d(xt, kt, k, s, p, d)
+    out.backward(dev(cot, dtype))
+    torch.cuda.synchronize()
+    return (out.detach().float().cpu().numpy(), xt.grad.float().cpu().numpy(), kt.grad.float().cpu().numpy())
+
+
+@pytest.mark.parametrize("name", CONV_CASES)
+def test_golden_forward_and_backward(name):
+    z = load_golden(name)
+    k, s, p, d = geom_of(z)
+    out, gi, gk = run_all(z["x"], z["kernel"], z["cot"], k, s, p, d)
+    assert out.dtype == np.float32
+    assert nmax(out, z["out"]) <= TOL, name
+    assert nmax(gi, z["grad_input_f64"]) <= TOL, name
+    assert nmax(gk, z["grad_kernel_f64"]) <= TOL, name
+    with torch.no_grad():                                   # no-grad route and native_impl flag: same kernel
+        o2 = pac.conv2d(dev(z["x"]), dev(z["kernel"]), k, s, p, d, native_impl=True)
+    assert np.array_equal(o2.cpu().numpy(), out)
+
+
+@pytest.mark.parametrize("name", golden_names("g9_nd2col_"))
+def test_golden_nd2col_bit_exact(name):
+    z = load_golden(name)
+    g = [int(v) for v in z["geom"]]
+    cols = pac.nd2col(dev(z["x"]), (g[0], g[1]), (g[2], g[3]), (g[4], g[5]), (g[8], g[9]), (g[6], g[7]), bool(g[10]))
+    assert tuple(cols.shape) == z["cols"].shape
+    assert np.array_equal(cols.cpu().numpy(), z["cols"])
+    c16 = pac.nd2col(dev(z["x"], torch.float16), (g[0], g[1]), (g[2], g[3]), (g[4], g[5]), (g[8], g[9]), (g[6], g[7]),
+                     bool(g[10]))
+    assert np.array_equal(c16.cpu().numpy(), z["cols"].astype(np.float16))
+
+
+def test_golden_fp16():
+    z = load_golden("g9_fp16")
+    k, s, p, d = geom_of(z)
+    with torch.no_grad():
+        out = pac.conv2d(dev(z["x"]), dev(z["kernel"]), k, s, p, d)
+    assert out.dtype == torch.float16
+    exact = porc.pac_conv2d_forward(z["x"], z["kernel"], k, s, p, d, dtype=np.float32)
+    got = out.float().cpu().numpy()
+    # fp32 accumulation, one rounding: within half an fp16 ulp of the exact sum, and at least as close as the reference
+    assert np.abs(got - exact).max() <= np.abs(exact).max() * 2.0 ** -11 + 1e-7
+    assert np.abs(got - exact).max() <= np.abs(z["out"].astype(np.float32) - exact).max() + 1e-7
+
+
+def _random_geometry(rng):
+    while True:
+        H, W = (int(v) for v in rng.integers(1, 48, 2))
+        k = tuple(int(v) for v in rng.integers(1, 6, 2))
+        s = tuple(int(v) for v in rng.integers(1, 4, 2))
+        p = tuple(int(v) for v in rng.integers(0, 5, 2))
+        d = tuple(int(v) for v in rng.integers(1, 4, 2))
+        if min(H + 2 * p[0] - d[0] * (k[0] - 1) - 1, W + 2 * p[1] - d[1] * (k[1] - 1) - 1) >= 0:
+            return H, W, k, s, p, d
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_geometry_vs_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    H, W, k, s, p, d = _random_geometry(rng)
+    B, C = int(rng.integers(1, 4)), int(rng.integers(1, 10))
+    CK = C if rng.integers(0, 2) else 1
+    Ho, Wo = porc.out_size((H, W), k, s, p, d)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kern = rng.standard_normal((B, CK, k[0], k[1], Ho, Wo)).astype(np.float32)
+    cot = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    out, gi, gk = run_all(x, kern, cot, k, s, p, d)
+    want = porc.pac_conv2d_forward(x, kern, k, s, p, d, dtype=np.float64)
+    wgi, wgk = porc.pac_conv2d_backward(x, kern, cot, k, s, p, d)
+    tag = (B, C, CK, H, W, k, s, p, d)
+    assert nmax(out, want) <= TOL, tag
+    assert nmax(gi, wgi) <= TOL, tag
+    assert nmax(gk, wgk) <= TOL, tag
+    cols = pac.nd2col(dev(x), k, s, p, 0, d).cpu().numpy()
+    assert np.array_equal(cols, porc.nd2col(x, k, s, p, 0, d)), tag
+
+
+def test_padding_zero_times_nonfinite_kernel_is_nan_like_unfold():
+    # F.unfold gives 0 in the padding and the reference multiplies it by the kernel: 0 * inf = NaN (pac.py:89-92)
+    x = np.ones((1, 1, 4, 4), np.float32)
+    kern = np.ones((1, 1, 3, 3, 4, 4), np.float32)
+    kern[0, 0, 0, 0, 0, 0] = np.inf            # tap (-1,-1) at the corner pixel looks at the padding
+    kern[0, 0, 1, 1, 2, 2] = np.inf            # centre tap at an interior pixel: a real inf
+    with torch.no_grad():
+        out = pac.conv2d(dev(x), dev(kern), 3, 1, 1, 1).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        want = porc.pac_conv2d_forward(x, kern, 3, 1, 1, 1)
+    assert np.isnan(out[0, 0, 0, 0]) and np.isposinf(out[0, 0, 2, 2])
+    assert np.array_equal(np.isnan(out), np.isnan(want)) and np.array_equal(np.isinf(out), np.isinf(want))
+
+
+@pytest.mark.parametrize("K", [3, 5, 7])
+def test_one_step_of_the_recurrence_equals_the_general_op(K):
+    """Cross-check of the two HIP paths at full frame size: CSPN_ours' step (CSPN_ours.py:47-53) is
+    conv2d(x, kernel, K, 1, K//2, 1) with the softmax kernel and a zero centre tap."""
+    B, H, W = 4, 228, 304
+    C = K * K - 1
+    gd = dev(orc.hash_normal(70 + K, 1, (B, C, H, W)))
+    x = dev(orc.hash_uniform(70 + K, 2, (B, 1, H, W), 0.0, 10.0))
+    with torch.no_grad():
+        step = pkg.CSPN_ours.AffinityPropagate(1)(x, gd)
+        sm = torch.softmax(gd, dim=1)
+        kern = torch.zeros(B, C + 1, H, W, device=DEV)
+        kern[:, :C // 2] = sm[:, :C // 2]
+        kern[:, C // 2 + 1:] = sm[:, C // 2:]
+        gen = pac.conv2d(x, kern.view(B, 1, K, K, H, W), K, 1, K // 2, 1)
+    assert nmax(gen.cpu().numpy(), step.cpu().numpy()) <= 2e-6
+
+
+def test_linearity_and_adjointness_at_full_size():
+    """Size-independent properties at the NYU frame: the op is bilinear, and <conv(x,k), g> = <x, grad_input(g,k)>
+    = <k, grad_kernel(g,x)> (the gradients are the exact adjoints)."""
+    B, C, H, W, K = 2, 3, 228, 304, 5
+    torch.manual_seed(3)
+    x = torch.randn(B, C, H, W, device=DEV, dtype=torch.float32)
+    k = torch.randn(B, 1, K, K, H, W, device=DEV, dtype=torch.float32)
+    g = torch.randn(B, C, H, W, device=DEV, dtype=torch.float32)
+    xr, kr = x.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    out = pac.conv2d(xr, kr, K, 1, K // 2, 1)
+    out.backward(g)
+    lhs = float((out.detach().double() * g.double()).sum())
+    assert abs(lhs - float((x.double() * xr.grad.double()).sum())) <= 1e-5 * abs(lhs) + 1e-3
+    assert abs(lhs - float((k.double() * kr.grad.double()).sum())) <= 1e-5 * abs(lhs) + 1e-3
+    with torch.no_grad():
+        o2 = pac.conv2d(2.0 * x, k, K, 1, K // 2, 1)
+    assert torch.equal(o2, 2.0 * out.detach())              # scaling by 2 is exact in binary floating point
+
+
+def test_only_needed_gradients_are_computed():
+    x = torch.randn(1, 2, 8, 8, device=DEV)
+    k = torch.randn(1, 1, 3, 3, 8, 8, device=DEV, requires_grad=True)
+    pac.conv2d(x, k, 3, 1, 1, 1).sum().backward()
+    assert k.grad is not None and x.grad is None
+    x2 = x.clone().requires_grad_(True)
+    pac.conv2d(x2, k.detach(), 3, 1, 1, 1).sum().backward()
+    assert x2.grad is not None
