@@ -79,6 +79,33 @@ def _forward(input, kernel, g):
     return out
 
 
+def _grad_input(grad_output, kernel, input_shape, g):
+    """fold(grad_out (x) kernel) -> [B,C,H,W]  (pac.py:104-113)."""
+    B, C, H, W = input_shape
+    dev = _require_device(grad_output, kernel)
+    go, k = grad_output.contiguous(), kernel.contiguous()
+    grad_input = torch.empty((B, C, H, W), dtype=go.dtype, device=dev)
+    with _device_guard(dev):
+        ok = _lib.lib().cspn_pac_conv2d_grad_input(_p(go), _p(k), _p(grad_input), _dt(go), B, C, k.size(1), H, W,
+                                                   ctypes.byref(g), _stream(dev))
+    _lib.check(ok, "cspn_pac_conv2d_grad_input")
+    return grad_input
+
+
+def _grad_kernel(grad_output, input, kernel_ch, g):
+    """grad_out * unfold(input), summed over channels for a shared kernel -> [B,kernel_ch,kh,kw,Ho,Wo]  (pac.py:115-119)."""
+    B, C, H, W = input.shape
+    dev = _require_device(grad_output, input)
+    go, x = grad_output.contiguous(), input.contiguous()
+    Ho, Wo = go.shape[-2:]
+    grad_kernel = torch.empty((B, kernel_ch, g.kh, g.kw, Ho, Wo), dtype=go.dtype, device=dev)
+    with _device_guard(dev):
+        ok = _lib.lib().cspn_pac_conv2d_grad_kernel(_p(go), _p(x), _p(grad_kernel), _dt(go), B, C, kernel_ch, H, W,
+                                                    ctypes.byref(g), _stream(dev))
+    _lib.check(ok, "cspn_pac_conv2d_grad_kernel")
+    return grad_kernel
+
+
 class Conv2dFn(Function):
     """pac.py:73-121.  Saves input / kernel only where the other one needs a gradient, as the reference does (:85-86)."""
 
@@ -97,26 +124,8 @@ class Conv2dFn(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         input, kernel = ctx.saved_tensors
-        g = ctx.geom
-        B, C, H, W = ctx.input_shape
-        dev = _require_device(grad_output)
-        go = grad_output.contiguous()
-        grad_input = grad_kernel = None
-        L = _lib.lib()
-        with _device_guard(dev):
-            if ctx.needs_input_grad[0]:
-                k = kernel.contiguous()
-                grad_input = torch.empty((B, C, H, W), dtype=go.dtype, device=dev)
-                ok = L.cspn_pac_conv2d_grad_input(_p(go), _p(k), _p(grad_input), _dt(go), B, C, ctx.kernel_ch, H, W,
-                                                  ctypes.byref(g), _stream(dev))
-                _lib.check(ok, "cspn_pac_conv2d_grad_input")
-            if ctx.needs_input_grad[1]:
-                x = input.contiguous()
-                Ho, Wo = go.shape[-2:]
-                grad_kernel = torch.empty((B, ctx.kernel_ch, g.kh, g.kw, Ho, Wo), dtype=go.dtype, device=dev)
-                ok = L.cspn_pac_conv2d_grad_kernel(_p(go), _p(x), _p(grad_kernel), _dt(go), B, C, ctx.kernel_ch, H, W,
-                                                   ctypes.byref(g), _stream(dev))
-                _lib.check(ok, "cspn_pac_conv2d_grad_kernel")
+        grad_input = _grad_input(grad_output, kernel, ctx.input_shape, ctx.geom) if ctx.needs_input_grad[0] else None
+        grad_kernel = _grad_kernel(grad_output, input, ctx.kernel_ch, ctx.geom) if ctx.needs_input_grad[1] else None
         return grad_input, grad_kernel, None, None, None, None
 
 

@@ -8,6 +8,9 @@
 // (C = 1, stride 1, "same" padding, T steps) does NOT come through here — cspn_propagate keeps it in LDS.
 #include "cspn_common.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 struct ConvArgs {
@@ -17,6 +20,7 @@ struct ConvArgs {
     int transposed;
     int cchunk;                          // channels per blockIdx.y
     int vec;                             // Wo % 4 == 0 and 16-byte (8 for f16) aligned bases: quad loads/stores
+    int force_scalar;                    // CSPN_PAC_SCALAR=1 in the environment: skip the tiled kernels (A/B, tests)
 };
 
 // source index along one axis for output index o and tap t, or -1 where the window sees a zero
@@ -111,6 +115,147 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd(const T* __restrict__ in, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, tiled
+// Stride 1, dilation 1, square K in {3,5,7} (any padding): the case every model in the reference uses, and the one
+// where the scalar kernel above is bound by its K*K cached loads per channel rather than by HBM.  A workgroup owns a
+// 64 x 16 output tile (one quad per thread).  Channels go through LDS CC at a time: the (64+K-1) x (16+K-1) input
+// patches of the NEXT batch are fetched into registers before the current batch is computed and committed to the
+// other LDS buffer afterwards (one barrier per batch, global latency hidden behind the FMAs); window rows come back
+// as aligned ds_read_b128.  Kernel taps: shared kernel and K <= 5 — loaded once, resident in registers for every
+// channel (HOIST); K = 7 — one tap row at a time inside the row loop, each row applied to the whole batch.
+constexpr int TILE_W = 64, TILE_H = 16;
+
+// CB = channels per LDS batch: 4, or 1 for single-channel chunks (fewer registers, higher occupancy: the C = 1 case
+// is a pure stream and lives on occupancy).
+template <typename T, int K, bool HOIST, int CB>
+__global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(const T* __restrict__ in, const T* __restrict__ kern,
+                                                                             T* __restrict__ out, ConvArgs a, int tiles_x) {
+    constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);     // LDS row pitch, a multiple of 4
+    constexpr int RH = TILE_H + K - 1;
+    constexpr int PATCH = RH * RW;
+    constexpr int NLD = (PATCH + 255) / 256;            // patch elements staged per thread and channel
+    constexpr int NQUAD = (K + 3 + 3) / 4;              // aligned quads covering the K+3 window columns
+    constexpr bool ROWWISE = K > 5;
+    constexpr int KR = ROWWISE ? K : K * K;
+    constexpr int ROW_UNROLL = ROWWISE ? 1 : K;         // row-wise: a real loop, or the tap loads are hoisted and spill
+    __shared__ __attribute__((aligned(16))) float tile[2][CB][PATCH];
+    const int tid = blockIdx.x;
+    const int ty = tid / tiles_x, tx = tid - ty * tiles_x;
+    const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+    const int qx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x0 = tx0 + 4 * qx, y = ty0 + ly;
+    const bool live = y < a.Ho && x0 < a.Wo;
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const size_t opix = (size_t)y * a.Wo + x0;
+
+    int goff[NLD];                                      // patch element -> offset in the input plane, -1 = zero padding
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int idx = threadIdx.x + 256 * n;
+        const int ry = idx / RW, rx = idx - ry * RW;
+        const int yi = ty0 - a.ph + ry, xi = tx0 - a.pw + rx;
+        goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) ? yi * a.W + xi : -1;
+    }
+    float pre[CB][NLD];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) {
+            const T* inb = in + ((size_t)b * a.C + min(c0 + cc, a.C - 1)) * iplane;
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) pre[cc][n] = (c0 + cc < c_end && goff[n] >= 0) ? ld1(inb + goff[n]) : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc)
+#pragma unroll
+            for (int n = 0; n < NLD; ++n)
+                if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = pre[cc][n];
+    };
+    float kr[KR][4];
+    auto load_taps = [&](int kc, int first, int n) {
+        const T* kp = kern + (((size_t)b * a.CK + kc) * (K * K) + first) * oplane + opix;
+#pragma unroll
+        for (int t = 0; t < n; ++t) {
+            if (a.vec) load_quad<T, true>(kp + (size_t)t * oplane, x0, a.Wo, kr[t]);
+            else load_quad<T, false>(kp + (size_t)t * oplane, x0, a.Wo, kr[t]);
+        }
+    };
+    auto window = [&](int buf, int cc, int row, float (&win)[4 * NQUAD]) {
+#pragma unroll
+        for (int n = 0; n < NQUAD; ++n) {
+            const v4f v = *(lds_cv4f_ptr)(&tile[buf][cc][row * RW + 4 * qx + 4 * n]);
+            win[4 * n] = v.x; win[4 * n + 1] = v.y; win[4 * n + 2] = v.z; win[4 * n + 3] = v.w;
+        }
+    };
+    auto store_out = [&](int c, const float (&acc)[4]) {
+        T* op = out + ((size_t)b * a.C + c) * oplane + opix;
+        if (a.vec) store_quad<T, true>(op, x0, a.Wo, acc);
+        else store_quad<T, false>(op, x0, a.Wo, acc);
+    };
+
+    if (HOIST && live) load_taps(0, 0, K * K);
+    fetch(c_begin);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; c += CB) {
+        const bool more = c + CB < c_end;
+        if (more) fetch(c + CB);
+        if (live) {
+            if constexpr (ROWWISE) {
+                float acc[CB][4];
+#pragma unroll
+                for (int cc = 0; cc < CB; ++cc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
+#pragma unroll 1
+                for (int i = 0; i < K; ++i) {
+                    if (a.CK == 1) load_taps(0, i * K, K);
+#pragma unroll
+                    for (int cc = 0; cc < CB; ++cc) {
+                        if (c + cc < c_end) {
+                            if (a.CK != 1) load_taps(c + cc, i * K, K);
+                            float win[4 * NQUAD];
+                            window(buf, cc, ly + i, win);
+#pragma unroll
+                            for (int j = 0; j < K; ++j)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(kr[j][e], win[j + e], acc[cc][e]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < CB; ++cc)
+                    if (c + cc < c_end) store_out(c + cc, acc[cc]);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < CB; ++cc) {
+                    if (c + cc < c_end) {
+                        if (!HOIST) load_taps(a.CK == 1 ? 0 : c + cc, 0, K * K);
+                        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll ROW_UNROLL
+                        for (int i = 0; i < K; ++i) {
+                            float win[4 * NQUAD];
+                            window(buf, cc, ly + i, win);
+#pragma unroll
+                            for (int j = 0; j < K; ++j)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[e] = fmaf(kr[ROWWISE ? j : i * K + j][e], win[j + e], acc[e]);
+                        }
+                        store_out(c + cc, acc);
+                    }
+                }
+            }
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dL/dkernel
 // thread = (output quad, tap); blockIdx.y = tap.  grad_kernel[b,c|0,i,j,y,x] = (sum_c) g[b,c,y,x] * in0[b,c,...]
 template <typename T, bool VEC, bool SHARED>
@@ -147,6 +292,90 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk(const T* __restrict__ gout,
         }
     }
     if constexpr (SHARED) store_quad<T, VEC>(gk + ((size_t)b * ntap + tap) * oplane + opix, x0, a.Wo, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dkernel, tiled
+// Same tile and geometry restrictions as pac_conv2d_fwd_tiled.  blockIdx.y = tap row i: the workgroup stages, for CC
+// channels at a time, the 16 input rows that tap row looks at, and every thread turns its grad_out quad into the K
+// kernel-gradient quads of that row (accumulated over channels in registers when the kernel is shared).
+template <typename T, int K, bool SHARED>
+__global__ __launch_bounds__(256) void pac_conv2d_gk_tiled(const T* __restrict__ gout, const T* __restrict__ in,
+                                                           T* __restrict__ gk, ConvArgs a, int tiles_x) {
+    constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);
+    constexpr int NQUAD = (K + 3 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[CC][TILE_H * RW];
+    const int tid = blockIdx.x;
+    const int ty = tid / tiles_x, tx = tid - ty * tiles_x;
+    const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+    const int qx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x0 = tx0 + 4 * qx, y = ty0 + ly;
+    const bool live = y < a.Ho && x0 < a.Wo;
+    const int b = blockIdx.z, i = blockIdx.y;
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const size_t opix = (size_t)y * a.Wo + x0;
+    float acc[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+    for (int c = 0; c < a.C; c += CC) {
+        const int nc = min(CC, a.C - c);
+        float g[CC][4];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (live && cc < nc) {
+                const T* gp = gout + ((size_t)b * a.C + c + cc) * oplane + opix;
+                if (a.vec) load_quad<T, true>(gp, x0, a.Wo, g[cc]);
+                else load_quad<T, false>(gp, x0, a.Wo, g[cc]);
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nc * TILE_H * RW; idx += 256) {
+            const int cc = idx / (TILE_H * RW), r = idx - cc * (TILE_H * RW);
+            const int ry = r / RW, rx = r - ry * RW;
+            const int yi = ty0 - a.ph + i + ry, xi = tx0 - a.pw + rx;
+            tile[cc][r] = ((unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
+                              ? ld1(in + ((size_t)b * a.C + c + cc) * iplane + (size_t)yi * a.W + xi) : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                if (cc < nc) {
+                    float win[4 * NQUAD];
+#pragma unroll
+                    for (int n = 0; n < NQUAD; ++n) {
+                        const v4f v = *(lds_cv4f_ptr)(&tile[cc][ly * RW + 4 * qx + 4 * n]);
+                        win[4 * n] = v.x; win[4 * n + 1] = v.y; win[4 * n + 2] = v.z; win[4 * n + 3] = v.w;
+                    }
+                    if constexpr (SHARED) {
+#pragma unroll
+                        for (int j = 0; j < K; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[j][e] += g[cc][e] * win[j + e];   // mul then add, as :117-119
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            float pr[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pr[e] = g[cc][e] * win[j + e];
+                            T* dst = gk + (((size_t)b * a.C + c + cc) * (K * K) + i * K + j) * oplane + opix;
+                            if (a.vec) store_quad<T, true>(dst, x0, a.Wo, pr);
+                            else store_quad<T, false>(dst, x0, a.Wo, pr);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (SHARED && live) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            T* dst = gk + ((size_t)b * (K * K) + i * K + j) * oplane + opix;
+            if (a.vec) store_quad<T, true>(dst, x0, a.Wo, acc[j]);
+            else store_quad<T, false>(dst, x0, a.Wo, acc[j]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ dL/dinput
@@ -288,6 +517,8 @@ int make_args(const char* who, int dtype, int B, int C, int CK, int H, int W, co
         return fail("%s: transposed geometry with padding > (k-1)*dilation is not defined (negative pad)", who);
     if (!out_size(H, W, *g, &r.Ho, &r.Wo)) return fail("%s: geometry gives an empty output for input %dx%d", who, H, W);
     r.WQ = ceil_div(r.Wo, 4);
+    const char* fs = getenv("CSPN_PAC_SCALAR");
+    r.force_scalar = fs && fs[0] == '1';
     if ((size_t)r.Ho * r.WQ > (size_t)1 << 30) return fail("%s: plane too large", who);
     *a = r;
     return 1;
@@ -309,8 +540,41 @@ bool aligned_for(const void* p, int dtype) {
     return (reinterpret_cast<uintptr_t>(p) & (dtype == CSPN_F16 ? 7 : 15)) == 0;
 }
 
+bool tiled_geometry(const ConvArgs& a) {
+    if ((size_t)a.H * a.W >= ((size_t)1 << 31)) return false;      // the tiled kernels keep plane offsets in int
+    return a.kh == a.kw && (a.kh == 3 || a.kh == 5 || a.kh == 7) && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1;
+}
+
+template <typename T, int K>
+int conv_forward_tiled(const T* in, const T* kern, T* out, ConvArgs a, hipStream_t st) {
+    const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+    // every channel chunk re-reads the kernel planes, so only split as far as filling the chip needs (~4 x 256 groups)
+    const size_t want = 1024, have = (size_t)tiles * a.B;
+    int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)a.C);
+    if (a.CK != 1) nchunk = (int)std::min<size_t>((4 * want + have - 1) / have, (size_t)a.C);   // nothing is re-read
+    a.cchunk = ceil_div(a.C, std::max(nchunk, 1));
+    const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
+    const bool hoist = a.CK == 1 && K <= 5;
+    if (a.cchunk == 1) {
+        if (hoist) pac_conv2d_fwd_tiled<T, K, true, 1><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
+        else pac_conv2d_fwd_tiled<T, K, false, 1><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
+    } else {
+        if (hoist) pac_conv2d_fwd_tiled<T, K, true, CC><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
+        else pac_conv2d_fwd_tiled<T, K, false, CC><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
+    }
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
 template <typename T>
 int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, hipStream_t st) {
+    if (tiled_geometry(a) && !a.force_scalar) {
+        const T* i = static_cast<const T*>(in);
+        const T* k = static_cast<const T*>(kern);
+        T* o = static_cast<T*>(out);
+        return a.kh == 3 ? conv_forward_tiled<T, 3>(i, k, o, a, st)
+             : a.kh == 5 ? conv_forward_tiled<T, 5>(i, k, o, a, st) : conv_forward_tiled<T, 7>(i, k, o, a, st);
+    }
     const int gx = ceil_div(a.Ho * a.WQ, 256);
     a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
     const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
@@ -326,8 +590,25 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
     return 1;
 }
 
+template <typename T, int K>
+int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
+    const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+    const dim3 grid(tiles, K, a.B), block(256);
+    if (a.CK == 1) pac_conv2d_gk_tiled<T, K, true><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
+    else pac_conv2d_gk_tiled<T, K, false><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
 template <typename T>
 int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStream_t st) {
+    if (tiled_geometry(a) && !a.force_scalar) {
+        const T* g = static_cast<const T*>(gout);
+        const T* i = static_cast<const T*>(in);
+        T* o = static_cast<T*>(gk);
+        return a.kh == 3 ? conv_gk_tiled<T, 3>(g, i, o, a, st)
+             : a.kh == 5 ? conv_gk_tiled<T, 5>(g, i, o, a, st) : conv_gk_tiled<T, 7>(g, i, o, a, st);
+    }
     const dim3 grid(ceil_div(a.Ho * a.WQ, 256), a.kh * a.kw, a.B), block(256);
     const T* g = static_cast<const T*>(gout);
     const T* i = static_cast<const T*>(in);

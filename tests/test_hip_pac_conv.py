@@ -115,6 +115,38 @@ def test_fuzz_geometry_vs_oracle(seed):
     assert np.array_equal(cols, porc.nd2col(x, k, s, p, 0, d)), tag
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_tiled_geometry_both_kernels(seed, monkeypatch):
+    """Stride 1 / dilation 1 / square K in {3,5,7} takes the LDS-tiled kernels; CSPN_PAC_SCALAR=1 forces the generic
+    ones.  Both must match the oracle on frames that span several 64 x 16 tiles, ragged edges included."""
+    rng = np.random.default_rng(2000 + seed)
+    K = (3, 5, 7)[seed % 3]
+    p = (int(rng.integers(0, K + 1)), int(rng.integers(0, K + 1)))
+    H, W = int(rng.integers(max(1, K - 2 * p[0]), 60)), int(rng.integers(max(1, K - 2 * p[1]), 200))
+    if seed % 4 == 0:
+        W = (W + 3) // 4 * 4 - 2 * p[1] + K - 1            # Wo % 4 == 0: the vector path
+        W = max(W, 4)
+    B, C = int(rng.integers(1, 3)), int(rng.integers(1, 11))
+    CK = C if seed % 2 else 1
+    dt = torch.float16 if seed % 6 == 5 else torch.float32
+    Ho, Wo = porc.out_size((H, W), K, 1, p, 1)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kern = (rng.standard_normal((B, CK, K, K, Ho, Wo)) * 0.3).astype(np.float32)
+    cot = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    if dt == torch.float16:
+        x, kern, cot = (v.astype(np.float16).astype(np.float32) for v in (x, kern, cot))
+    want = porc.pac_conv2d_forward(x, kern, K, 1, p, 1, dtype=np.float64)
+    wgi, wgk = porc.pac_conv2d_backward(x, kern, cot, K, 1, p, 1)
+    tol = 2e-3 if dt == torch.float16 else TOL
+    tag = (B, C, CK, H, W, K, p, str(dt))
+    for scalar in ("0", "1"):
+        monkeypatch.setenv("CSPN_PAC_SCALAR", scalar)
+        out, gi, gk = run_all(x, kern, cot, K, 1, p, 1, dt)
+        assert nmax(out, want) <= tol, (tag, scalar)
+        assert nmax(gi, wgi) <= tol, (tag, scalar)
+        assert nmax(gk, wgk) <= tol, (tag, scalar)
+
+
 def test_padding_zero_times_nonfinite_kernel_is_nan_like_unfold():
     # F.unfold gives 0 in the padding and the reference multiplies it by the kernel: 0 * inf = NaN (pac.py:89-92)
     x = np.ones((1, 1, 4, 4), np.float32)

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Roofline of the general pixel-adaptive conv op (cspn_pac_conv2d & gradients) on the GPU box (developer tool).
+
+    python tools/bench_pac_conv.py [--json gpurun_out/pac_conv.json]
+
+Algorithmic bytes per output pixel: kernel_ch*kh*kw (kernel) + C (input, read once) + C (output) elements for the
+forward; the gradients move the same tensors the other way.  Also times the reference's formulation (F.unfold *
+kernel, summed — pac.py:89-92) with torch ops on the same GPU for scale.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cspn_monodepth_amd.base import pac            # noqa: E402
+from tools.tune import timed                       # noqa: E402
+
+PEAK = 8000.0
+CASES = [   # name, B, C, CK, H, W, K, stride, pad, dil, dtype
+    ("c1_k5_same (CSPN_ours step)", 24, 1, 1, 228, 304, 5, 1, 2, 1, torch.float32),
+    ("c1_k3_same", 24, 1, 1, 228, 304, 3, 1, 1, 1, torch.float32),
+    ("c1_k5_same_f16", 24, 1, 1, 228, 304, 5, 1, 2, 1, torch.float16),
+    ("c64_k5_shared", 8, 64, 1, 228, 304, 5, 1, 2, 1, torch.float32),
+    ("c64_k3_perch", 8, 64, 64, 228, 304, 3, 1, 1, 1, torch.float32),
+    ("c32_k3_stride2", 8, 32, 1, 228, 304, 3, 2, 1, 1, torch.float32),
+    ("c32_k3_dil2", 8, 32, 1, 228, 304, 3, 1, 2, 2, torch.float32),
+    ("c16_k7_shared", 8, 16, 1, 228, 304, 7, 1, 3, 1, torch.float32),
+]
+
+
+def unfold_formulation(x, k, K, s, p, d):
+    B, C = x.shape[:2]
+    cols = torch.nn.functional.unfold(x, K, d, p, s).view(B, C, K, K, *k.shape[-2:])
+    return (cols * k).sum(dim=(2, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default="")
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    rows = []
+    for name, B, C, CK, H, W, K, s, p, d, dt in CASES:
+        Ho, Wo = pac.output_size((H, W), K, s, p, d)
+        x = torch.randn(B, C, H, W, device=dev, dtype=dt)
+        k = torch.randn(B, CK, K, K, Ho, Wo, device=dev, dtype=dt)
+        g = torch.randn(B, C, Ho, Wo, device=dev, dtype=dt)
+        es = x.element_size()
+        fwd_bytes = (k.numel() + x.numel() + g.numel()) * es
+        with torch.no_grad():
+            t_f = timed(lambda: pac.conv2d(x, k, K, s, p, d), args.reps)
+            t_u = timed(lambda: unfold_formulation(x, k, K, s, p, d), 5)
+        geom = pac._geometry(K, s, p, d)                 # the two gradient kernels alone, without autograd's host time
+        t_gi = timed(lambda: pac._grad_input(g, k, tuple(x.shape), geom), args.reps)
+        t_gk = timed(lambda: pac._grad_kernel(g, x, CK, geom), args.reps)
+        t_b = t_gi + t_gk
+        bwd_bytes = (2 * k.numel() + 2 * x.numel() + 2 * g.numel()) * es     # gi: g,k -> gx ; gk: g,x -> gk
+        row = dict(case=name, B=B, C=C, kernel_ch=CK, H=H, W=W, K=K, stride=s, padding=p, dilation=d,
+                   dtype=str(dt).split(".")[-1], fwd_us=t_f, fwd_GBs=fwd_bytes / t_f / 1e3, fwd_frac=fwd_bytes / t_f / 1e3 / PEAK,
+                   bwd_us=t_b, bwd_GBs=bwd_bytes / t_b / 1e3, bwd_frac=bwd_bytes / t_b / 1e3 / PEAK,
+                   grad_input_us=t_gi, grad_kernel_us=t_gk, torch_unfold_us=t_u)
+        rows.append(row)
+        print("%-30s fwd %8.1f us %6.0f GB/s (%4.1f%%)   bwd %8.1f us %6.0f GB/s (%4.1f%%) [gi %.1f gk %.1f]   torch unfold fwd %9.1f us (x%.1f)" % (
+            name, t_f, row["fwd_GBs"], 100 * row["fwd_frac"], t_b, row["bwd_GBs"], 100 * row["bwd_frac"], t_gi, t_gk, t_u, t_u / t_f), flush=True)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
