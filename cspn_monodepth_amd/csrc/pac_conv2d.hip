@@ -115,21 +115,36 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd(const T* __restrict__ in, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ forward, tiled
+// ------------------------------------------------------------------------------------------------ forward / dL/dinput, tiled
 // Stride 1, dilation 1, square K in {3,5,7} (any padding): the case every model in the reference uses, and the one
-// where the scalar kernel above is bound by its K*K cached loads per channel rather than by HBM.  A workgroup owns a
-// 64 x 16 output tile (one quad per thread).  Channels go through LDS CC at a time: the (64+K-1) x (16+K-1) input
-// patches of the NEXT batch are fetched into registers before the current batch is computed and committed to the
-// other LDS buffer afterwards (one barrier per batch, global latency hidden behind the FMAs); window rows come back
-// as aligned ds_read_b128.  Kernel taps: shared kernel and K <= 5 — loaded once, resident in registers for every
-// channel (HOIST); K = 7 — one tap row at a time inside the row loop, each row applied to the whole batch.
+// where the scalar kernels are bound by their K*K cached loads per channel rather than by HBM.  A workgroup owns a
+// 64 x 16 tile of the destination plane (one quad per thread).  Channels go through LDS CB at a time: the
+// (64+K-1) x (16+K-1) source patches of the NEXT batch are fetched into registers before the current batch is
+// computed and committed to the other LDS buffer afterwards (one barrier per batch, global latency hidden behind the
+// FMAs); window rows come back as aligned ds_read_b128.  Kernel taps: shared kernel and K <= 5 — loaded once,
+// resident in registers for every channel (HOIST); K = 7 — one tap row at a time inside the row loop, each row
+// applied to the whole batch.  CB = 1 serves single-channel chunks (fewer registers: the C = 1 case is a pure stream
+// and lives on occupancy).
+//
+//   forward    : source = input,    destination = out [Ho,Wo]; tap (i,j) of destination pixel q is kernel[i,j] AT q.
+//   TRANSPOSED : source = grad_out, destination = grad_input [H,W]; the fold of pac.py:104-113 as a gather — input
+//                pixel q receives grad_out[s] * kernel[K-1-i', K-1-j'][s] from the source pixel s = q + (i',j') + origin,
+//                so the taps are read where the SOURCE pixel lives (unaligned: 4 scalar loads per tap).
 constexpr int TILE_W = 64, TILE_H = 16;
 
-// CB = channels per LDS batch: 4, or 1 for single-channel chunks (fewer registers, higher occupancy: the C = 1 case
-// is a pure stream and lives on occupancy).
-template <typename T, int K, bool HOIST, int CB>
-__global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(const T* __restrict__ in, const T* __restrict__ kern,
-                                                                             T* __restrict__ out, ConvArgs a, int tiles_x) {
+struct TiledArgs {
+    int B, C, CK, cchunk;
+    int src_h, src_w;        // plane the LDS patches come from
+    int dst_h, dst_w;        // plane the tile lives on
+    int org_y, org_x;        // patch origin relative to the tile origin (forward: -pad; transposed: pad - (K-1))
+    int k_h, k_w;            // kernel planes: always [Ho, Wo]
+    int k_vec, dst_vec;      // aligned quads possible on the kernel planes (forward only) / the destination
+    int tiles_x;
+};
+
+template <typename T, int K, bool HOIST, int CB, bool TRANSPOSED>
+__global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
+                                                                         T* __restrict__ dst, TiledArgs a) {
     constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);     // LDS row pitch, a multiple of 4
     constexpr int RH = TILE_H + K - 1;
     constexpr int PATCH = RH * RW;
@@ -140,31 +155,31 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(con
     constexpr int ROW_UNROLL = ROWWISE ? 1 : K;         // row-wise: a real loop, or the tap loads are hoisted and spill
     __shared__ __attribute__((aligned(16))) float tile[2][CB][PATCH];
     const int tid = blockIdx.x;
-    const int ty = tid / tiles_x, tx = tid - ty * tiles_x;
+    const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
     const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
     const int qx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int x0 = tx0 + 4 * qx, y = ty0 + ly;
-    const bool live = y < a.Ho && x0 < a.Wo;
+    const bool live = y < a.dst_h && x0 < a.dst_w;
     const int b = blockIdx.z;
     const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
-    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
-    const size_t opix = (size_t)y * a.Wo + x0;
+    const size_t kplane = (size_t)a.k_h * a.k_w, splane = (size_t)a.src_h * a.src_w, dplane = (size_t)a.dst_h * a.dst_w;
+    const size_t dpix = (size_t)y * a.dst_w + x0;
 
-    int goff[NLD];                                      // patch element -> offset in the input plane, -1 = zero padding
+    int goff[NLD];                                      // patch element -> offset in the source plane, -1 = zero
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
         const int idx = threadIdx.x + 256 * n;
         const int ry = idx / RW, rx = idx - ry * RW;
-        const int yi = ty0 - a.ph + ry, xi = tx0 - a.pw + rx;
-        goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W) ? yi * a.W + xi : -1;
+        const int yi = ty0 + a.org_y + ry, xi = tx0 + a.org_x + rx;
+        goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.src_h && (unsigned)xi < (unsigned)a.src_w) ? yi * a.src_w + xi : -1;
     }
     float pre[CB][NLD];
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
-            const T* inb = in + ((size_t)b * a.C + min(c0 + cc, a.C - 1)) * iplane;
+            const T* sp = src + ((size_t)b * a.C + min(c0 + cc, a.C - 1)) * splane;
 #pragma unroll
-            for (int n = 0; n < NLD; ++n) pre[cc][n] = (c0 + cc < c_end && goff[n] >= 0) ? ld1(inb + goff[n]) : 0.f;
+            for (int n = 0; n < NLD; ++n) pre[cc][n] = (c0 + cc < c_end && goff[n] >= 0) ? ld1(sp + goff[n]) : 0.f;
         }
     };
     auto commit = [&](int buf) {
@@ -175,12 +190,29 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(con
                 if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = pre[cc][n];
     };
     float kr[KR][4];
+    // taps [first, first+n) in window order (row-major over (i',j')) of kernel channel kc -> kr[0..n)
     auto load_taps = [&](int kc, int first, int n) {
-        const T* kp = kern + (((size_t)b * a.CK + kc) * (K * K) + first) * oplane + opix;
+        const T* kb = kern + ((size_t)b * a.CK + kc) * (K * K) * kplane;
+        if constexpr (!TRANSPOSED) {
+            const T* kp = kb + (size_t)first * kplane + dpix;
 #pragma unroll
-        for (int t = 0; t < n; ++t) {
-            if (a.vec) load_quad<T, true>(kp + (size_t)t * oplane, x0, a.Wo, kr[t]);
-            else load_quad<T, false>(kp + (size_t)t * oplane, x0, a.Wo, kr[t]);
+            for (int t = 0; t < n; ++t) {
+                if (a.k_vec) load_quad<T, true>(kp + (size_t)t * kplane, x0, a.k_w, kr[t]);
+                else load_quad<T, false>(kp + (size_t)t * kplane, x0, a.k_w, kr[t]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < n; ++t) {
+                const int w = first + t, wi = w / K, wj = w - wi * K;      // window position (i',j'); constants after unrolling
+                const int sy = y + a.org_y + wi;
+                const T* kp = kb + (size_t)(K * K - 1 - w) * kplane + (size_t)sy * a.k_w;   // flipped tap, source row
+                const bool rowok = (unsigned)sy < (unsigned)a.k_h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sx = x0 + e + a.org_x + wj;
+                    kr[t][e] = (rowok && (unsigned)sx < (unsigned)a.k_w) ? ld1(kp + sx) : 0.f;
+                }
+            }
         }
     };
     auto window = [&](int buf, int cc, int row, float (&win)[4 * NQUAD]) {
@@ -190,10 +222,10 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(con
             win[4 * n] = v.x; win[4 * n + 1] = v.y; win[4 * n + 2] = v.z; win[4 * n + 3] = v.w;
         }
     };
-    auto store_out = [&](int c, const float (&acc)[4]) {
-        T* op = out + ((size_t)b * a.C + c) * oplane + opix;
-        if (a.vec) store_quad<T, true>(op, x0, a.Wo, acc);
-        else store_quad<T, false>(op, x0, a.Wo, acc);
+    auto store_dst = [&](int c, const float (&acc)[4]) {
+        T* op = dst + ((size_t)b * a.C + c) * dplane + dpix;
+        if (a.dst_vec) store_quad<T, true>(op, x0, a.dst_w, acc);
+        else store_quad<T, false>(op, x0, a.dst_w, acc);
     };
 
     if (HOIST && live) load_taps(0, 0, K * K);
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(con
                 }
 #pragma unroll
                 for (int cc = 0; cc < CB; ++cc)
-                    if (c + cc < c_end) store_out(c + cc, acc[cc]);
+                    if (c + cc < c_end) store_dst(c + cc, acc[cc]);
             } else {
 #pragma unroll
                 for (int cc = 0; cc < CB; ++cc) {
@@ -243,9 +275,9 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_fwd_tiled(con
 #pragma unroll
                             for (int j = 0; j < K; ++j)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[e] = fmaf(kr[ROWWISE ? j : i * K + j][e], win[j + e], acc[e]);
+                                for (int e = 0; e < 4; ++e) acc[e] = fmaf(kr[i * K + j][e], win[j + e], acc[e]);
                         }
-                        store_out(c + cc, acc);
+                        store_dst(c + cc, acc);
                     }
                 }
             }
@@ -374,6 +406,124 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk_tiled(const T* __restrict__
             T* dst = gk + ((size_t)b * (K * K) + i * K + j) * oplane + opix;
             if (a.vec) store_quad<T, true>(dst, x0, a.Wo, acc[j]);
             else store_quad<T, false>(dst, x0, a.Wo, acc[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dkernel, whole window
+// K <= 5: one workgroup produces all K*K kernel-gradient planes of its tile in one pass — the input patches and the
+// grad_out quads of the next channel batch are prefetched exactly as in pac_conv2d_tiled; with a shared kernel the
+// K*K quads accumulate over every channel in registers and are written once.
+template <typename T, int K, bool SHARED, int CB>
+__global__ __launch_bounds__(256) void pac_conv2d_gk_window(const T* __restrict__ gout, const T* __restrict__ in,
+                                                            T* __restrict__ gk, TiledArgs a) {
+    constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);
+    constexpr int RH = TILE_H + K - 1;
+    constexpr int PATCH = RH * RW;
+    constexpr int NLD = (PATCH + 255) / 256;
+    constexpr int NQUAD = (K + 3 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[2][CB][PATCH];
+    const int tid = blockIdx.x;
+    const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
+    const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+    const int qx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x0 = tx0 + 4 * qx, y = ty0 + ly;
+    const bool live = y < a.dst_h && x0 < a.dst_w;
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t splane = (size_t)a.src_h * a.src_w, dplane = (size_t)a.dst_h * a.dst_w;
+    const size_t dpix = (size_t)y * a.dst_w + x0;
+
+    int goff[NLD];
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int idx = threadIdx.x + 256 * n;
+        const int ry = idx / RW, rx = idx - ry * RW;
+        const int yi = ty0 + a.org_y + ry, xi = tx0 + a.org_x + rx;
+        goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.src_h && (unsigned)xi < (unsigned)a.src_w) ? yi * a.src_w + xi : -1;
+    }
+    float pre[CB][NLD], gpre[CB][4], g[CB][4];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) {
+            const int c = min(c0 + cc, a.C - 1);
+            const T* sp = in + ((size_t)b * a.C + c) * splane;
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) pre[cc][n] = (c0 + cc < c_end && goff[n] >= 0) ? ld1(sp + goff[n]) : 0.f;
+            if (live && c0 + cc < c_end) {
+                const T* gp = gout + ((size_t)b * a.C + c) * dplane + dpix;
+                if (a.dst_vec) load_quad<T, true>(gp, x0, a.dst_w, gpre[cc]);
+                else load_quad<T, false>(gp, x0, a.dst_w, gpre[cc]);
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) {
+#pragma unroll
+            for (int n = 0; n < NLD; ++n)
+                if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = pre[cc][n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[cc][e] = gpre[cc][e];
+        }
+    };
+    float acc[K * K][4];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    fetch(c_begin);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; c += CB) {
+        const bool more = c + CB < c_end;
+        float gc[CB][4];                                  // this batch's grad_out quads (g is overwritten by commit below)
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gc[cc][e] = g[cc][e];
+        if (more) fetch(c + CB);
+        if (live) {
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) {
+                if (c + cc < c_end) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        float win[4 * NQUAD];
+#pragma unroll
+                        for (int n = 0; n < NQUAD; ++n) {
+                            const v4f v = *(lds_cv4f_ptr)(&tile[buf][cc][(ly + i) * RW + 4 * qx + 4 * n]);
+                            win[4 * n] = v.x; win[4 * n + 1] = v.y; win[4 * n + 2] = v.z; win[4 * n + 3] = v.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            if constexpr (SHARED) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i * K + j][e] = fmaf(gc[cc][e], win[j + e], acc[i * K + j][e]);
+                            } else {
+                                float pr[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) pr[e] = gc[cc][e] * win[j + e];
+                                T* dp = gk + (((size_t)b * a.C + c + cc) * (K * K) + i * K + j) * dplane + dpix;
+                                if (a.dst_vec) store_quad<T, true>(dp, x0, a.dst_w, pr);
+                                else store_quad<T, false>(dp, x0, a.dst_w, pr);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (SHARED && live) {
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) {
+            T* dp = gk + ((size_t)b * (K * K) + t) * dplane + dpix;
+            if (a.dst_vec) store_quad<T, true>(dp, x0, a.dst_w, acc[t]);
+            else store_quad<T, false>(dp, x0, a.dst_w, acc[t]);
         }
     }
 }
@@ -545,25 +695,46 @@ bool tiled_geometry(const ConvArgs& a) {
     return a.kh == a.kw && (a.kh == 3 || a.kh == 5 || a.kh == 7) && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1;
 }
 
-template <typename T, int K>
-int conv_forward_tiled(const T* in, const T* kern, T* out, ConvArgs a, hipStream_t st) {
-    const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+// Launch of pac_conv2d_tiled for the forward (transposed = false) or the input gradient (true).
+template <typename T, int K, bool TRANSPOSED>
+int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst_vec, hipStream_t st) {
+    TiledArgs t{};
+    t.B = a.B; t.C = a.C; t.CK = a.CK;
+    t.k_h = a.Ho; t.k_w = a.Wo;
+    if (TRANSPOSED) {
+        t.src_h = a.Ho; t.src_w = a.Wo; t.dst_h = a.H; t.dst_w = a.W;
+        t.org_y = a.ph - (K - 1); t.org_x = a.pw - (K - 1);
+    } else {
+        t.src_h = a.H; t.src_w = a.W; t.dst_h = a.Ho; t.dst_w = a.Wo;
+        t.org_y = -a.ph; t.org_x = -a.pw;
+    }
+    t.k_vec = a.vec; t.dst_vec = dst_vec;
+    t.tiles_x = ceil_div(t.dst_w, TILE_W);
+    const int tiles = t.tiles_x * ceil_div(t.dst_h, TILE_H);
     // every channel chunk re-reads the kernel planes, so only split as far as filling the chip needs (~4 x 256 groups)
     const size_t want = 1024, have = (size_t)tiles * a.B;
     int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)a.C);
     if (a.CK != 1) nchunk = (int)std::min<size_t>((4 * want + have - 1) / have, (size_t)a.C);   // nothing is re-read
-    a.cchunk = ceil_div(a.C, std::max(nchunk, 1));
-    const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
-    const bool hoist = a.CK == 1 && K <= 5;
-    if (a.cchunk == 1) {
-        if (hoist) pac_conv2d_fwd_tiled<T, K, true, 1><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
-        else pac_conv2d_fwd_tiled<T, K, false, 1><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
+    t.cchunk = ceil_div(a.C, std::max(nchunk, 1));
+    const dim3 grid(tiles, ceil_div(a.C, t.cchunk), a.B), block(256);
+    constexpr bool CAN_HOIST = K <= 5;                   // the whole window in registers
+    const bool hoist = CAN_HOIST && a.CK == 1;
+    if (t.cchunk == 1) {
+        if (hoist) pac_conv2d_tiled<T, K, CAN_HOIST, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
+        else pac_conv2d_tiled<T, K, false, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
     } else {
-        if (hoist) pac_conv2d_fwd_tiled<T, K, true, CC><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
-        else pac_conv2d_fwd_tiled<T, K, false, CC><<<grid, block, 0, st>>>(in, kern, out, a, tiles_x);
+        if (hoist) pac_conv2d_tiled<T, K, CAN_HOIST, CC, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
+        else pac_conv2d_tiled<T, K, false, CC, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
     }
     HIP_OK(hipGetLastError());
     return 1;
+}
+
+template <typename T, bool TRANSPOSED>
+int launch_tiled_k(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst_vec, hipStream_t st) {
+    return a.kh == 3 ? launch_tiled<T, 3, TRANSPOSED>(src, kern, dst, a, dst_vec, st)
+         : a.kh == 5 ? launch_tiled<T, 5, TRANSPOSED>(src, kern, dst, a, dst_vec, st)
+                     : launch_tiled<T, 7, TRANSPOSED>(src, kern, dst, a, dst_vec, st);
 }
 
 template <typename T>
@@ -572,8 +743,7 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
         const T* i = static_cast<const T*>(in);
         const T* k = static_cast<const T*>(kern);
         T* o = static_cast<T*>(out);
-        return a.kh == 3 ? conv_forward_tiled<T, 3>(i, k, o, a, st)
-             : a.kh == 5 ? conv_forward_tiled<T, 5>(i, k, o, a, st) : conv_forward_tiled<T, 7>(i, k, o, a, st);
+        return launch_tiled_k<T, false>(i, k, o, a, a.vec, st);
     }
     const int gx = ceil_div(a.Ho * a.WQ, 256);
     a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
@@ -593,6 +763,31 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
 template <typename T, int K>
 int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
     const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+    if constexpr (K <= 5) {
+        // whole-window kernel; a shared kernel pins all channels to one workgroup, so it needs enough tiles to fill the
+        // chip — small launches keep the tap-row split below (K x the workgroups)
+        if (a.CK != 1 || (size_t)tiles * a.B >= 256) {
+            TiledArgs t{};
+            t.B = a.B; t.C = a.C; t.CK = a.CK;
+            t.src_h = a.H; t.src_w = a.W; t.dst_h = a.Ho; t.dst_w = a.Wo; t.k_h = a.Ho; t.k_w = a.Wo;
+            t.org_y = -a.ph; t.org_x = -a.pw;
+            t.k_vec = t.dst_vec = a.vec;
+            t.tiles_x = tiles_x;
+            int nchunk = 1;
+            if (a.CK != 1) nchunk = (int)std::min<size_t>((4096 + (size_t)tiles * a.B - 1) / ((size_t)tiles * a.B), (size_t)a.C);
+            t.cchunk = ceil_div(a.C, nchunk);
+            const dim3 grid(tiles, ceil_div(a.C, t.cchunk), a.B), block(256);
+            if (a.CK == 1) {
+                if (a.C == 1) pac_conv2d_gk_window<T, K, true, 1><<<grid, block, 0, st>>>(g, in, gk, t);
+                else pac_conv2d_gk_window<T, K, true, CC><<<grid, block, 0, st>>>(g, in, gk, t);
+            } else {
+                if (t.cchunk == 1) pac_conv2d_gk_window<T, K, false, 1><<<grid, block, 0, st>>>(g, in, gk, t);
+                else pac_conv2d_gk_window<T, K, false, CC><<<grid, block, 0, st>>>(g, in, gk, t);
+            }
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     const dim3 grid(tiles, K, a.B), block(256);
     if (a.CK == 1) pac_conv2d_gk_tiled<T, K, true><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
     else pac_conv2d_gk_tiled<T, K, false><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
@@ -624,6 +819,9 @@ int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStr
 
 template <typename T>
 int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int in_vec, hipStream_t st) {
+    if (tiled_geometry(a) && !a.force_scalar && (size_t)a.Ho * a.Wo < ((size_t)1 << 31))
+        return launch_tiled_k<T, true>(static_cast<const T*>(gout), static_cast<const T*>(kern), static_cast<T*>(gin), a,
+                                       in_vec, st);
     const int in_wq = ceil_div(a.W, 4);
     const int gx = ceil_div(a.H * in_wq, 256);
     a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
