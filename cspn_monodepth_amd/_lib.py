@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
@@ -29,7 +29,7 @@ EXPORTS = (
     "cspn_transpose_weights",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
-    "cspn_pac_out_size", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col",
+    "cspn_pac_out_size", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
 )
 
 
@@ -123,6 +123,8 @@ def _declare(lib):
     lib.cspn_pac_conv2d_grad_input.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
     lib.cspn_pac_conv2d_grad_kernel.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
     lib.cspn_pac_nd2col.argtypes = [vp, vp, ci, ci, ci, ci, ci, geom, vp]
+    lib.cspn_unpool2d.argtypes = [vp, vp, ci, cl, ci, ci, ci, ci, ci, vp]
+    lib.cspn_unpool2d_backward.argtypes = [vp, vp, ci, cl, ci, ci, ci, ci, ci, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes"):

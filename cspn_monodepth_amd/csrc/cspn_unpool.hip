@@ -1,0 +1,94 @@
+// cspn_unpool.hip — zero-insertion un-pooling of the UNet decoders.
+//
+//   out[p, s*h, s*w] = in[p, h, w], 0 elsewhere, cropped to oH x oW      network/unet_ours.py:138-150 (grouped
+//   conv_transpose2d with a one-hot s x s weight + crop) and network/unet_cspn_nyu.py:202-213 (nearest upsample times a
+//   checkerboard mask the reference builds with an O(H*W) Python double loop on every call).
+// One streaming pass: each thread writes a quad of the output (all of it, zeros included, so no memset) and the
+// backward is the strided gather (it does not reproduce 0 * NaN from non-finite gradients at dropped positions).  HBM-bound: (1 + s*s) elements per input pixel forward.
+#include "cspn_common.hpp"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_fwd(const T* __restrict__ in, T* __restrict__ out, int H, int W, int s,
+                                                  int oH, int oW, int oWQ, int vec) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= oH * oWQ) return;
+    const int y = q / oWQ, x0 = (q - y * oWQ) * 4;
+    const size_t p = blockIdx.y;
+    // Inserted positions hold in * 0, not a literal 0: both reference formulations multiply (one-hot conv_transpose
+    // weight / checkerboard mask), so a non-finite activation turns its whole s x s block into NaN there.
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* row = in + (p * H + y / s) * (size_t)W;
+    const float rowgate = y % s == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        if (x < oW) v[e] = ld1(row + x / s) * (x % s == 0 ? rowgate : 0.f);      // x / s < W because oW <= s * W
+    }
+    T* dst = out + (p * oH + y) * (size_t)oW + x0;
+    if (vec) {
+        st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < oW) st1(dst + e, v[e]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_bwd(const T* __restrict__ gout, T* __restrict__ gin, int H, int W, int s,
+                                                  int oH, int oW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int h = i / W, w = i - h * W;
+    const size_t p = blockIdx.y;
+    const int y = h * s, x = w * s;
+    st1(gin + p * H * (size_t)W + i, (y < oH && x < oW) ? ld1(gout + (p * oH + y) * (size_t)oW + x) : 0.f);
+}
+
+int check(const char* who, int dtype, long planes, int H, int W, int s, int oH, int oW) {
+    if (dtype != CSPN_F32 && dtype != CSPN_F16) return fail("%s: dtype must be CSPN_F32 or CSPN_F16", who);
+    if (planes < 1 || planes > 65535 || H < 1 || W < 1) return fail("%s: bad shape (planes=%ld in [1,65535], H=%d, W=%d)", who, planes, H, W);
+    if (s < 1) return fail("%s: scale must be >= 1", who);
+    if (oH < 1 || oW < 1 || (long)oH > (long)s * H || (long)oW > (long)s * W)
+        return fail("%s: output %dx%d must lie in [1, scale*H] x [1, scale*W] = %ldx%ld", who, oH, oW, (long)s * H, (long)s * W);
+    if ((long)oH * ((oW + 3) / 4) > (1L << 30) || (long)H * W > (1L << 30)) return fail("%s: plane too large", who);
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cspn_unpool2d(const void* input, void* out, int dtype, long planes, int H, int W, int scale, int oH, int oW,
+                  cspn_stream_t stream) {
+    if (!check("cspn_unpool2d", dtype, planes, H, W, scale, oH, oW)) return 0;
+    if (!input || !out) return fail("cspn_unpool2d: null pointer");
+    const int oWQ = ceil_div(oW, 4);
+    const int vec = oW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & (dtype == CSPN_F16 ? 7 : 15)) == 0;
+    const dim3 grid(ceil_div(oH * oWQ, 256), (unsigned)planes), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == CSPN_F16)
+        unpool_fwd<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(input), static_cast<__half*>(out), H, W, scale, oH, oW, oWQ, vec);
+    else
+        unpool_fwd<float><<<grid, block, 0, st>>>(static_cast<const float*>(input), static_cast<float*>(out), H, W, scale, oH, oW, oWQ, vec);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int cspn_unpool2d_backward(const void* grad_out, void* grad_input, int dtype, long planes, int H, int W, int scale,
+                           int oH, int oW, cspn_stream_t stream) {
+    if (!check("cspn_unpool2d_backward", dtype, planes, H, W, scale, oH, oW)) return 0;
+    if (!grad_out || !grad_input) return fail("cspn_unpool2d_backward: null pointer");
+    const dim3 grid(ceil_div(H * W, 256), (unsigned)planes), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == CSPN_F16)
+        unpool_bwd<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(grad_out), static_cast<__half*>(grad_input), H, W, scale, oH, oW);
+    else
+        unpool_bwd<float><<<grid, block, 0, st>>>(static_cast<const float*>(grad_out), static_cast<float*>(grad_input), H, W, scale, oH, oW);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+}  // extern "C"

@@ -224,6 +224,16 @@ int cspn_pac_conv2d_grad_kernel(const void* grad_out, const void* input, void* g
 int cspn_pac_nd2col(const void* input, void* cols, int dtype, int B, int C, int H, int W,
                     const cspn_conv_geometry* geom, cspn_stream_t stream);
 
+/* ---- zero-insertion un-pooling -------------------------------------- *
+ * out[p, s*h, s*w] = in[p, h, w], 0 elsewhere, cropped to oH x oW (1 <= oH <= s*H, 1 <= oW <= s*W); p runs over the
+ * B*C planes (<= 65535).  network/unet_ours.py:138-150 (grouped conv_transpose2d with a one-hot weight + crop) and
+ * network/unet_cspn_nyu.py:202-213 (nearest upsample x checkerboard mask).  The kernel writes the zeros too: `out`
+ * needs no memset.  The backward is the strided gather grad_in[p,h,w] = grad_out[p, s*h, s*w] (0 past the crop). */
+int cspn_unpool2d(const void* input, void* out, int dtype, long planes, int H, int W, int scale, int oH, int oW,
+                  cspn_stream_t stream);
+int cspn_unpool2d_backward(const void* grad_out, void* grad_input, int dtype, long planes, int H, int W, int scale,
+                           int oH, int oW, cspn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
