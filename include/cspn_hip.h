@@ -226,7 +226,7 @@ int cspn_pac_nd2col(const void* input, void* cols, int dtype, int B, int C, int 
 
 /* ---- zero-insertion un-pooling -------------------------------------- *
  * out[p, s*h, s*w] = in[p, h, w], 0 elsewhere, cropped to oH x oW (1 <= oH <= s*H, 1 <= oW <= s*W); p runs over the
- * B*C planes (<= 65535).  network/unet_ours.py:138-150 (grouped conv_transpose2d with a one-hot weight + crop) and
+ * B*C planes (fewer than 2^31 output quads per call).  network/unet_ours.py:138-150 (grouped conv_transpose2d with a one-hot weight + crop) and
  * network/unet_cspn_nyu.py:202-213 (nearest upsample x checkerboard mask).  The kernel writes the zeros too: `out`
  * needs no memset.  The backward is the strided gather grad_in[p,h,w] = grad_out[p, s*h, s*w] (0 past the crop). */
 int cspn_unpool2d(const void* input, void* out, int dtype, long planes, int H, int W, int scale, int oH, int oW,

@@ -66,6 +66,24 @@ def main():
         rows.append(row)
         print("%-30s fwd %8.1f us %6.0f GB/s (%4.1f%%)   bwd %8.1f us %6.0f GB/s (%4.1f%%) [gi %.1f gk %.1f]   torch unfold fwd %9.1f us (x%.1f)" % (
             name, t_f, row["fwd_GBs"], 100 * row["fwd_frac"], t_b, row["bwd_GBs"], 100 * row["bwd_frac"], t_gi, t_gk, t_u, t_u / t_f), flush=True)
+    # zero-insertion un-pooling at the five decoder stages of unet_cspn_nyu (B = 24)
+    from cspn_monodepth_amd.network import up_pooling as up
+    for (H, W, oh, ow, C) in ((8, 10, 15, 19, 1024), (15, 19, 29, 38, 512), (29, 38, 57, 76, 256), (57, 76, 114, 152, 128),
+                              (114, 152, 228, 304, 64)):
+        x = torch.randn(24, C, H, W, device=dev)
+        g = torch.randn(24, C, oh, ow, device=dev)
+        wgt = torch.zeros(C, 1, 2, 2, device=dev)
+        wgt[:, :, 0, 0] = 1
+        with torch.no_grad():
+            t_f = timed(lambda: up.up_pooling(x, 2, oh, ow), args.reps)
+            t_r = timed(lambda: torch.nn.functional.conv_transpose2d(x, wgt, stride=2, groups=C)[:, :, :oh, :ow], 5)
+            t_b = timed(lambda: up._UpPooling.backward(type("c", (), {"geom": (tuple(x.shape), 2, oh, ow)}), g), args.reps)
+        fb = (x.numel() + g.numel()) * 4
+        row = dict(case="unpool_%dx%d_c%d" % (oh, ow, C), fwd_us=t_f, fwd_GBs=fb / t_f / 1e3, fwd_frac=fb / t_f / 1e3 / PEAK,
+                   bwd_us=t_b, bwd_GBs=fb / t_b / 1e3, torch_conv_transpose_us=t_r)
+        rows.append(row)
+        print("unpool -> %3dx%-3d C=%-4d fwd %7.1f us %6.0f GB/s (%4.1f%%)   bwd %7.1f us %6.0f GB/s   conv_transpose2d formulation %8.1f us (x%.1f)" % (
+            oh, ow, C, t_f, row["fwd_GBs"], 100 * row["fwd_frac"], t_b, row["bwd_GBs"], t_r, t_r / t_f), flush=True)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(rows, f, indent=1)
