@@ -8,7 +8,7 @@ its ``ValueError('Incompatible input and kernel sizes.')``.  Every call runs lib
 cspn_pac_conv2d_grad_input / _grad_kernel, cspn_pac_nd2col in include/cspn_hip.h); there is no unfold, no im2col
 buffer ([B, C*K*K, L] in the reference) and no CPU path.
 
-Differences, all documented in DESIGN.md §9:
+Differences:
   * ``native_impl`` selects between two formulations of the same sum in the reference (identical outputs, golden
     manifest ``branches_max_abs`` = 0); here both values run the one HIP kernel.
   * ``Conv2dFn.backward`` works (the reference's needs the THNN backend removed in torch 1.0).
