@@ -20,6 +20,7 @@ HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include",
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
+ABI_VERSION = 3          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -107,15 +108,15 @@ def _declare(lib):
     lib.cspn_propagate_scored.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci,
                                           ctypes.POINTER(cspn_plan), vp]
     lib.cspn_propagate_transposed.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_plan), vp]
-    lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
+    lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
                                                   vp, vp, ci,
                                                   ctypes.POINTER(cspn_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
     lib.cspn_pac_grad_guided.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.cspn3_backward_tail.argtypes = [vp, vp, vp, vp, vp, cl, cl, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.cspn_pac_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.cspn3_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, cl, cl, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.cspn_pac_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, ci, vp]
     geom = ctypes.POINTER(cspn_conv_geometry)
     lib.cspn_pac_out_size.argtypes = [ci, ci, geom, ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -143,7 +144,7 @@ def lib():
                         "cspn_monodepth_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % SO_PATH)
                 _lib = _declare(ctypes.CDLL(SO_PATH))
-                if _lib.cspn_abi_version() != 2:
+                if _lib.cspn_abi_version() != ABI_VERSION:
                     raise RuntimeError("cspn_monodepth_amd: ABI version mismatch")
     return _lib
 

@@ -10,8 +10,8 @@ namespace {
 // gw_j[p] = (1-m) sum_t G_{t+1}[p] d_t[p+off_j];  gd0[p] = G_0[p] + m sum_{t>=1} G_t[p]
 template <int K, typename DT>
 __global__ void cspn_grad_weights_kernel(const DT* __restrict__ d0, const DT* __restrict__ dhist,
-                                         const float* __restrict__ ghist, const DT* __restrict__ sparse,
-                                         float* __restrict__ gw, float* __restrict__ gd0,
+                                         const float* __restrict__ g_T, const float* __restrict__ ghist,
+                                         const DT* __restrict__ sparse, float* __restrict__ gw, float* __restrict__ gd0,
                                          int B, int H, int W, int T) {
     constexpr int R = K / 2;
     constexpr int NT = K * K - 1;
@@ -27,7 +27,7 @@ __global__ void cspn_grad_weights_kernel(const DT* __restrict__ d0, const DT* __
         float gsum = 0.f;
         for (int t = 0; t < T; ++t) {
             const DT* d = (t == 0) ? d0 : dhist + (size_t)(t - 1) * total;
-            const float G = ghist[(size_t)(T - 1 - t) * total + i];   // G_{t+1}
+            const float G = (t == T - 1) ? g_T[i] : ghist[(size_t)(T - 2 - t) * total + i];   // G_{t+1}
             gsum += G;
             int j = 0;
 #pragma unroll
@@ -45,7 +45,7 @@ __global__ void cspn_grad_weights_kernel(const DT* __restrict__ d0, const DT* __
         const float m = sparse ? sgnf(ld1(sparse + i)) : 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) gw[((size_t)b * NT + j) * HW + p] = (1.f - m) * acc[j];
-        gd0[i] = ghist[(size_t)T * total + i] + m * gsum;        // G_0 + m sum_{t>=1} G_t
+        gd0[i] = (T > 0 ? ghist[(size_t)(T - 1) * total + i] : g_T[i]) + m * gsum;        // G_0 + m sum_{t>=1} G_t
     }
 }
 
@@ -120,7 +120,8 @@ __global__ void cspn_pac_grad_guided_kernel(const WT* __restrict__ wk, const flo
 struct TailArgs {
     const void* d0;       // [B,H,W]   DT
     const void* dhist;    // [T,B,H,W] DT  (d_1..d_T)
-    const float* ghist;   // [T+1,B,H,W] backward order: ghist[s] = G_{T-s}
+    const float* g_T;     // [B,H,W] G_T = dL/d(d_T), the incoming gradient (read in place, never copied)
+    const float* ghist;   // [T,B,H,W] backward order: ghist[s] = G_{T-1-s}, what the reverse sweep wrote
     const void* sparse;   // [B,H,W] DT or null
     const void* w;        // [B,NT,H,W] WT tap planes (variants 1, 2)
     const float* S;       // [B,H,W] (variant 1)
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
             const int t = t0 + u;
             const bool tv = live && t < T;
             const DT* d = (t == 0) ? d0 : dh + (size_t)(tv ? t - 1 : 0) * plane;
-            Gq[u] = tv ? ld4(a.ghist + (size_t)(T - 1 - t) * plane + off) : z4;
+            const float* gsrc = (t == T - 1) ? a.g_T : a.ghist + (size_t)(tv ? T - 2 - t : 0) * plane;      // G_{t+1}
+            Gq[u] = tv ? ld4(gsrc + off) : z4;
 #pragma unroll
             for (int rr = 0; rr < 2 * R + 1; ++rr) {
                 const int row = y + rr - R;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
         for (int e = 0; e < 4; ++e) om[e] = 1.f - mm[e];
     }
     {
-        const float4 G0 = ld4(a.ghist + (size_t)T * plane + off);
+        const float4 G0 = ld4((T > 0 ? a.ghist + (size_t)(T - 1) * plane : a.g_T) + off);
         st4(a.gd0 + off, make_float4(G0.x + mm[0] * gsum[0], G0.y + mm[1] * gsum[1], G0.z + mm[2] * gsum[2],
                                      G0.w + mm[3] * gsum[3]));
     }
@@ -351,7 +353,7 @@ int launch_tail_typed(const TailArgs& a, int variant, int d_dtype, int w_dtype, 
 }
 
 bool tail_vector_ok(const TailArgs& a) {
-    return (a.W % 4 == 0) && aligned16(a.d0) && (!a.dhist || aligned16(a.dhist)) && aligned16(a.ghist) &&
+    return (a.W % 4 == 0) && aligned16(a.d0) && (!a.dhist || aligned16(a.dhist)) && (!a.ghist || aligned16(a.ghist)) && aligned16(a.g_T) &&
            (!a.sparse || aligned16(a.sparse)) && (!a.w || aligned16(a.w)) && (!a.S || aligned16(a.S)) &&
            (!a.guidance || aligned16(a.guidance)) && aligned16(a.gout) && aligned16(a.gd0) &&
            (a.g_bs % 4 == 0) && (a.g_cs % 4 == 0);
@@ -361,13 +363,13 @@ bool tail_vector_ok(const TailArgs& a) {
 
 extern "C" {
 
-int cspn_grad_weights(const void* d0, const void* dhist, const float* ghist, const void* sparse, float* gw,
-                      float* gd0, int d_dtype, int B, int H, int W, int K, int T, cspn_stream_t stream) {
-    if (!d0 || !ghist || !gw || !gd0 || (T > 1 && !dhist)) return fail("cspn_grad_weights: NULL pointer");
+int cspn_grad_weights(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
+                      float* gw, float* gd0, int d_dtype, int B, int H, int W, int K, int T, cspn_stream_t stream) {
+    if (!d0 || !g_T || !gw || !gd0 || (T > 1 && !dhist) || (T > 0 && !ghist)) return fail("cspn_grad_weights: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     {   // vector path: the fused tail without an epilogue (dL/dw written as is)
         TailArgs a{};
-        a.d0 = d0; a.dhist = dhist; a.ghist = ghist; a.sparse = sparse; a.gout = gw; a.gd0 = gd0;
+        a.d0 = d0; a.dhist = dhist; a.g_T = g_T; a.ghist = ghist; a.sparse = sparse; a.gout = gw; a.gd0 = gd0;
         a.B = B; a.H = H; a.W = W; a.T = T;
         if (tail_vector_ok(a) && (K == 3 || K == 5 || K == 7)) {
             switch (K) {
@@ -382,11 +384,11 @@ int cspn_grad_weights(const void* d0, const void* dhist, const float* ghist, con
     if (K == KV) {                                                                                             \
         if (d_dtype == CSPN_F32)                                                                               \
             hipLaunchKernelGGL((cspn_grad_weights_kernel<KV, float>), dim3(grid), dim3(256), 0, st,            \
-                               static_cast<const float*>(d0), static_cast<const float*>(dhist), ghist,         \
+                               static_cast<const float*>(d0), static_cast<const float*>(dhist), g_T, ghist,    \
                                static_cast<const float*>(sparse), gw, gd0, B, H, W, T);                        \
         else                                                                                                   \
             hipLaunchKernelGGL((cspn_grad_weights_kernel<KV, __half>), dim3(grid), dim3(256), 0, st,           \
-                               static_cast<const __half*>(d0), static_cast<const __half*>(dhist), ghist,       \
+                               static_cast<const __half*>(d0), static_cast<const __half*>(dhist), g_T, ghist,  \
                                static_cast<const __half*>(sparse), gw, gd0, B, H, W, T);                       \
         HIP_OK(hipGetLastError());                                                                             \
         return 1;                                                                                              \
@@ -439,25 +441,25 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
     return fail("cspn_pac_grad_guided: unsupported K=%d", K);
 }
 
-int cspn3_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
                         const void* guidance, long bs, long cs, int C, const void* w8, const float* s,
                         void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T, cspn_stream_t stream) {
-    if (!d0 || !ghist || !guidance || !w8 || !s || !grad_guidance || !gd0 || (T > 1 && !dhist))
+    if (!d0 || !g_T || !guidance || !w8 || !s || !grad_guidance || !gd0 || (T > 1 && !dhist) || (T > 0 && !ghist))
         return fail("cspn3_backward_tail: NULL pointer");
     TailArgs a{};
-    a.d0 = d0; a.dhist = dhist; a.ghist = ghist; a.sparse = sparse; a.w = w8; a.S = s; a.guidance = guidance;
+    a.d0 = d0; a.dhist = dhist; a.g_T = g_T; a.ghist = ghist; a.sparse = sparse; a.w = w8; a.S = s; a.guidance = guidance;
     a.gout = grad_guidance; a.gd0 = gd0; a.g_bs = bs; a.g_cs = cs; a.B = B; a.H = H; a.W = W; a.T = T; a.C = C;
     if (!tail_vector_ok(a)) return fail("cspn3_backward_tail needs W %% 4 == 0 and 16-byte aligned tensors; use "
                                         "cspn_grad_weights + cspn3_grad_guidance");
     return launch_tail_typed<3>(a, 1, dtype, dtype, static_cast<hipStream_t>(stream));
 }
 
-int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse, const void* wk,
+int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse, const void* wk,
                            void* grad_guided, float* gd0, int d_dtype, int w_dtype, int B, int H, int W, int K, int T,
                            cspn_stream_t stream) {
-    if (!d0 || !ghist || !wk || !grad_guided || !gd0 || (T > 1 && !dhist)) return fail("cspn_pac_backward_tail: NULL pointer");
+    if (!d0 || !g_T || !wk || !grad_guided || !gd0 || (T > 1 && !dhist) || (T > 0 && !ghist)) return fail("cspn_pac_backward_tail: NULL pointer");
     TailArgs a{};
-    a.d0 = d0; a.dhist = dhist; a.ghist = ghist; a.sparse = sparse; a.w = wk; a.gout = grad_guided; a.gd0 = gd0;
+    a.d0 = d0; a.dhist = dhist; a.g_T = g_T; a.ghist = ghist; a.sparse = sparse; a.w = wk; a.gout = grad_guided; a.gd0 = gd0;
     a.B = B; a.H = H; a.W = W; a.T = T;
     if (!tail_vector_ok(a)) return fail("cspn_pac_backward_tail needs W %% 4 == 0 and 16-byte aligned tensors; use "
                                         "cspn_grad_weights + cspn_pac_grad_guided");

@@ -25,6 +25,7 @@ struct PropArgs {
     const void* w;       // [B,NT,H,W] tap planes, or (WSRC=1) the guidance tensor itself
     long g_bs, g_cs;     // WSRC=1: guidance batch / channel strides in elements
     void* w_out;         // WSRC=1: optional tap volume receiving the derived weights of the interior quads
+    float* s_out;        // WSRC=1: optional [B,H,W] f32 receiving the normaliser S of the interior quads (backward needs it)
     const void* target;  // SCORE=1: ground-truth depth [B,H,W] (DT) scored against the final state
     double* macc;        // SCORE=1: [nslots][10] metric accumulators (cspn_metrics_accumulate layout)
     int nslots;
@@ -238,11 +239,13 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                 else { wreg[i][j][0] = fabsf(q0); wreg[i][j][1] = fabsf(q1); wreg[i][j][2] = fabsf(q2); wreg[i][j][3] = fabsf(q3); }
             }
             // S in the reference's channel order k = 0..7 (tap 7..0), then true division; 0 for padding quads
+            float Sq[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float S = wreg[i][7][e];
 #pragma unroll
                 for (int k = 1; k < 8; ++k) S += wreg[i][7 - k][e];
+                Sq[e] = S;
                 float av[8], qv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) av[j] = wreg[i][j][e];
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                 WT* wo = static_cast<WT*>(a.w_out) + (size_t)b * Taps<WT>::image_elems(NT, HW);
                 store_taps_quad<NT>(wo, off, HW, wreg[i]);
             }
+            if (a.s_out && ((interior >> i) & 1u)) st4(a.s_out + (size_t)b * HW + off, make_float4(Sq[0], Sq[1], Sq[2], Sq[3]));
         }
         if (BLEND && r < wr) {
             const float4 m = ok ? sgn4(ld4(spg + off)) : z4;
@@ -703,7 +707,7 @@ template <int K, typename WT, typename DT>
 int propagate_typed(const void* w, const void* d0, const void* sparse, void* out, void* history, void* work,
                     int B, int H, int W, int T, int blend, const cspn_plan* user, hipStream_t st,
                     int wsrc = 0, long g_bs = 0, long g_cs = 0, const void* target = nullptr, double* macc = nullptr,
-                    int nslots = 0, void* w_out = nullptr, int Wv = 0) {
+                    int nslots = 0, void* w_out = nullptr, int Wv = 0, float* s_out = nullptr) {
     if (Wv < 0 || Wv > W) return fail("W_valid=%d outside (0, W=%d]", Wv, W);
     if (Wv > 0 && Wv < W && (W % 4 != 0)) return fail("row padding (W_valid < W) needs a pitch W %% 4 == 0");
     const size_t plane_bytes = (size_t)B * H * W * sizeof(DT);
@@ -743,7 +747,8 @@ int propagate_typed(const void* w, const void* d0, const void* sparse, void* out
             // from-guidance with a weight buffer: the first launch derives + publishes the weights, the rest stream them
             const bool derive = (wsrc == 1) && (launch_idx == 0 || !w_out);
             L.a.w = (wsrc == 1 && !derive) ? w_out : w;
-            L.a.w_out = (derive && n_launch > 1) ? w_out : nullptr;
+            L.a.w_out = (derive && (n_launch > 1 || s_out)) ? w_out : nullptr;     // s_out: the backward wants the volume too
+            L.a.s_out = (derive && launch_idx == 0) ? s_out : nullptr;
             L.a.g_bs = g_bs; L.a.g_cs = g_cs; L.a.d_in = src; L.a.sparse = sparse; L.a.d0 = d0;
             L.a.d_out = history ? nullptr : dst;
             L.a.hist = hist_base;
@@ -870,8 +875,8 @@ int cspn_propagate_transposed(const void* w, int w_dtype, const float* g_T, cons
     return fail("cspn_propagate_transposed: unsupported K=%d / w_dtype=%d", K, w_dtype);
 }
 
-int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, void* w8_out, const void* d0,
-                                  const void* sparse, void* out, void* history, void* work, int d_dtype, int B, int H,
+int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, long cs, void* w8_out, float* s_out,
+                                  const void* d0, const void* sparse, void* out, void* history, void* work, int d_dtype, int B, int H,
                                   int W, int W_valid, int T, int blend, const void* target, double* acc, int nslots,
                                   const cspn_plan* plan, cspn_stream_t stream) {
     if ((target || acc) && (!target || !acc || nslots < 1 || !w8_out || history || !aligned16(target) || g_dtype != d_dtype))
@@ -882,13 +887,14 @@ int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long bs, lo
     if (blend != CSPN_BLEND_NONE && !sparse) return fail("cspn3_propagate_from_guidance: blend needs sparse");
     if ((cs & 3) || (bs & 3)) return fail("cspn3_propagate_from_guidance: guidance strides must be multiples of 4 elements");
     if (w8_out && !aligned16(w8_out)) return fail("cspn3_propagate_from_guidance: w8_out must be 16-byte aligned");
+    if (s_out && (!aligned16(s_out) || !w8_out)) return fail("cspn3_propagate_from_guidance: s_out needs w8_out and 16-byte alignment");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g_dtype == CSPN_F32 && d_dtype == CSPN_F32)
-        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid);
+        return propagate_typed<3, float, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid, s_out);
     if (g_dtype == CSPN_F16 && d_dtype == CSPN_F16)
-        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid);
+        return propagate_typed<3, __half, __half>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid, s_out);
     if (g_dtype == CSPN_F16 && d_dtype == CSPN_F32)
-        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid);
+        return propagate_typed<3, __half, float>(guidance, d0, sparse, out, history, work, B, H, W, T, blend, plan, st, 1, bs, cs, target, acc, nslots, w8_out, W_valid, s_out);
     return fail("cspn3_propagate_from_guidance: unsupported dtypes g=%d d=%d", g_dtype, d_dtype);
 }
 

@@ -395,9 +395,12 @@ def from_guidance_supported(guidance, d0, sparse, plan=None):
 
 
 def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, plan=None, publish_weights=True,
-                            score=None, valid_w=0):
+                            score=None, valid_w=0, return_weights=False):
     """3x3 variant without a prepare pass: every launch derives the normalised weights from `guidance`
-    (cspn3_propagate_from_guidance).  Same results, bit for bit, as cspn3_prepare + propagate."""
+    (cspn3_propagate_from_guidance).  Same results, bit for bit, as cspn3_prepare + propagate.
+
+    return_weights=True (the training forward) also returns the published tap volume and the normaliser S the
+    first launch wrote: (d_T, history, w8, S)."""
     dev = _require_device(guidance, d0, sparse)
     B, C, H, W = guidance.shape
     if C < 8:
@@ -422,9 +425,10 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
         if log is not None:
             ev0, ev1 = log.pair()
             ev0.record(torch.cuda.current_stream(dev))
-        w8 = _weight_buffer(B, 8, H, W, g.dtype, dev) if publish_weights else None
+        w8 = _weight_buffer(B, 8, H, W, g.dtype, dev) if (publish_weights or return_weights) else None
+        S_out = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_weights else None
         tg, acc = score if score is not None else (None, None)
-        ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(w8), _p(d0), _p(sparse), _p(out),
+        ok = L.cspn3_propagate_from_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), _p(w8), _p(S_out), _p(d0), _p(sparse), _p(out),
                                              _p(hist), _p(work), _dt(d0), B, H, W, int(valid_w), T, int(blend),
                                              _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                              _plan_ptr(3, plan), _stream(dev))
@@ -433,9 +437,8 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
             S = resolve_plan(3, B, H, W, T, keep_history, plan)["steps_per_launch"]
             log.append((ev0, ev1, -(-T // max(S, 1)), S))
     _lib.check(ok, "cspn3_propagate_from_guidance")
-    if hist is not None:
-        return hist[T - 1], hist
-    return out, None
+    res = (hist[T - 1], hist) if hist is not None else (out, None)
+    return res + (w8, S_out) if return_weights else res
 
 
 def transpose_weights(w, K, H, W):
@@ -450,12 +453,16 @@ def transpose_weights(w, K, H, W):
 
 def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
     """G_T = dL/dout, G_t = stencil^T((1-m) G_{t+1}): the forward kernel on the transposed weights.
-    Returns ghist [T+1,B,H,W] f32 in backward order (ghist[s] = G_{T-s})."""
+    Returns (g_T [B,H,W] f32 — grad_out itself, not a copy —, ghist [T,B,H,W] f32 in backward order:
+    ghist[s] = G_{T-1-s}; None when T == 0)."""
     dev = w.device
     B, H, W = grad_out.shape[0], grad_out.shape[-2], grad_out.shape[-1]
-    ghist = torch.empty((T + 1, B, H, W), dtype=torch.float32, device=dev)
-    ghist[0].copy_(grad_out.reshape(B, H, W))
+    g_T = grad_out.reshape(B, H, W)
+    if g_T.data_ptr() % 16:
+        g_T = g_T.clone()
+    ghist = None
     if T > 0:
+        ghist = torch.empty((T, B, H, W), dtype=torch.float32, device=dev)
         sp32 = None if sparse is None else sparse.float()
         L = _lib.lib()
         p = None
@@ -464,33 +471,33 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
         if p is not None and not p["force_scalar"] and (p["quads_per_thread"], p["threads"]) in _TRANSPOSED_INSTANCES[K]:
             # transposed recurrence straight on the forward tap volume (no transposed copy)
             with _device_guard(dev):
-                ok = L.cspn_propagate_transposed(_p(w), _dt(w), _p(ghist[0]), _p(sp32), _p(ghist[1]), B, H, W,
+                ok = L.cspn_propagate_transposed(_p(w), _dt(w), _p(g_T), _p(sp32), _p(ghist), B, H, W,
                                                  int(valid_w), int(K), T, int(sparse is not None),
                                                  _plan_ptr(K, plan), _stream(dev))
             _lib.check(ok, "cspn_propagate_transposed")
         else:
             wT = transpose_weights(w, K, H, W)
             with _device_guard(dev):
-                ok = L.cspn_propagate(_p(wT), _dt(wT), _p(ghist[0]), _p(sp32), None, _p(ghist[1]), None,
+                ok = L.cspn_propagate(_p(wT), _dt(wT), _p(g_T), _p(sp32), None, _p(ghist), None,
                                       CSPN_F32, B, H, W, int(valid_w), int(K), T,
                                       BLEND_PREMASK if sparse is not None else BLEND_NONE,
                                       _plan_ptr(K, plan), _stream(dev))
             _lib.check(ok, "cspn_propagate(backward)")
-    return ghist
+    return g_T, ghist
 
 
 def _tail_vector_ok(W, *tensors):
     return W % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
 
 
-def _grad_weights(w, K, T, d0, dhist, sparse, ghist):
+def _grad_weights(w, K, T, d0, dhist, sparse, g_T, ghist):
     """Unfused dL/dw + dL/dd0 (any shape / alignment)."""
     B, H, W = d0.shape
     NT = K * K - 1
     gw = torch.empty((B, NT, H, W), dtype=torch.float32, device=w.device)
     gd0 = torch.empty((B, H, W), dtype=torch.float32, device=w.device)
     with _device_guard(w.device):
-        ok = _lib.lib().cspn_grad_weights(_p(d0), _p(dhist), _p(ghist), _p(sparse), _p(gw), _p(gd0), _dt(d0),
+        ok = _lib.lib().cspn_grad_weights(_p(d0), _p(dhist), _p(g_T), _p(ghist), _p(sparse), _p(gw), _p(gd0), _dt(d0),
                                           B, H, W, int(K), T, _stream(w.device))
     _lib.check(ok, "cspn_grad_weights")
     return gw, gd0
@@ -518,8 +525,15 @@ class CSPN3Function(torch.autograd.Function):
             # inference: no separate prepare pass (the first launch derives and publishes the weights)
             out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, valid_w=valid_w)
             return out.unsqueeze(1)
-        w8, S, g = cspn3_prepare(guidance, want_s=need_grad, valid_w=valid_w)
-        out, hist = propagate(w8, d0, sp, 3, prop_time, blend, keep_history=need_grad, plan=plan, valid_w=valid_w)
+        if need_grad and _FROM_GUIDANCE and prop_time > 0 and from_guidance_supported(guidance, d0, sp, plan):
+            # training: the first launch derives the weights, publishes them and S for the backward, and the loop keeps
+            # the T depth planes — one pass over the guidance instead of a prepare pass + a re-read of the volume
+            g = guidance
+            out, hist, w8, S = propagate_from_guidance(g, d0, sp, prop_time, blend, keep_history=True, plan=plan,
+                                                       valid_w=valid_w, return_weights=True)
+        else:
+            w8, S, g = cspn3_prepare(guidance, want_s=need_grad, valid_w=valid_w)
+            out, hist = propagate(w8, d0, sp, 3, prop_time, blend, keep_history=need_grad, plan=plan, valid_w=valid_w)
         if need_grad:
             ctx.save_for_backward(g, w8, S, d0, sp, hist)
             ctx.prop_time, ctx.plan, ctx.valid_w = int(prop_time), plan, int(valid_w)
@@ -532,16 +546,16 @@ class CSPN3Function(torch.autograd.Function):
         B, C, H, W = g.shape
         T = ctx.prop_time
         L = _lib.lib()
-        ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
+        g_T, ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
         gg = torch.empty_like(g)
         if _tail_vector_ok(W, g, w8, S, d0, sp, hist, gg) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
             gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)
             with _device_guard(g.device):
-                ok = L.cspn3_backward_tail(_p(d0), _p(hist), _p(ghist), _p(sp), _p(g), g.stride(0), g.stride(1), C,
+                ok = L.cspn3_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(g), g.stride(0), g.stride(1), C,
                                            _p(w8), _p(S), _p(gg), _p(gd0), _dt(g), B, H, W, T, _stream(g.device))
             _lib.check(ok, "cspn3_backward_tail")
         else:
-            gw, gd0 = _grad_weights(w8, 3, T, d0, hist, sp, ghist)
+            gw, gd0 = _grad_weights(w8, 3, T, d0, hist, sp, g_T, ghist)
             with _device_guard(g.device):
                 ok = L.cspn3_grad_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), C, _p(w8), _dt(w8),
                                            _p(S), _p(gw), _p(gg), B, H, W, _stream(g.device))
@@ -581,16 +595,16 @@ class PACFunction(torch.autograd.Function):
         K, T = ctx.K, ctx.prop_time
         NT = K * K - 1
         L = _lib.lib()
-        ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
+        g_T, ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
         gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
         if _tail_vector_ok(W, wk, d0, sp, hist, gg):
             gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
             with _device_guard(wk.device):
-                ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
+                ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
                                               _dt(wk), B, H, W, K, T, _stream(wk.device))
             _lib.check(ok, "cspn_pac_backward_tail")
         else:
-            gw, gx0 = _grad_weights(wk, K, T, d0, hist, sp, ghist)
+            gw, gx0 = _grad_weights(wk, K, T, d0, hist, sp, g_T, ghist)
             with _device_guard(wk.device):
                 ok = L.cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, K, _stream(wk.device))
             _lib.check(ok, "cspn_pac_grad_guided")

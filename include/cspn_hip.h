@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 2
+#define CSPN_ABI_VERSION 3
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -116,18 +116,21 @@ int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void
                           int d_dtype, int B, int H, int W, int W_valid, int K, int T, int blend,
                           const void* target, double* acc, int nslots, const cspn_plan* plan, cspn_stream_t stream);
 
-/* 3x3 variant, inference: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
+/* 3x3 variant: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
  * weights from the raw guidance (same arithmetic, bit-identical results), so the 8 weight planes are never
  * written to or re-read from HBM.  Arguments as cspn3_prepare (guidance, strides) + cspn_propagate.
  * w8_out_or_null: NULL = every launch re-derives the weights (no weight volume at all); a [B,8,H,W] tap volume of
  * g_dtype = the FIRST launch derives the weights and also publishes them there, the following launches stream
  * them (one prepare pass and one read of the volume saved).
+ * s_out_or_null: optional [B,H,W] f32 receiving the normaliser S (as cspn3_prepare's s_or_null; needs w8_out): with
+ * `history` this is the training forward — weights, S and the T depth planes the backward needs, no prepare pass.
  * target/acc/nslots: optional scoring of d_T as in cspn_propagate_scored (needs w8_out, no history, more than
  * one launch, g_dtype == d_dtype).
  * Needs W % 4 == 0 and 16-byte aligned tensors (returns 0 otherwise: use the two-call form).
  * blend: CSPN_BLEND_NONE or CSPN_BLEND_SPARSE.  Replaces all of CSPN_new.py:29-92 for a forward pass. */
 int cspn3_propagate_from_guidance(const void* guidance, int g_dtype, long g_batch_stride, long g_chan_stride,
-                                  void* w8_out_or_null, const void* d0, const void* sparse, void* out, void* history, void* work,
+                                  void* w8_out_or_null, float* s_out_or_null, const void* d0, const void* sparse, void* out,
+                                  void* history, void* work,
                                   int d_dtype, int B, int H, int W, int W_valid, int T, int blend,
                                   const void* target_or_null, double* acc_or_null, int nslots,
                                   const cspn_plan* plan, cspn_stream_t stream);
@@ -151,9 +154,9 @@ int cspn_transpose_weights(const void* w, void* wT, int w_dtype, int B, int H, i
 /* gw[b][j][p] = (1-m[p]) * sum_{t=0}^{T-1} G_{t+1}[p] * d_t[p+off_j]      (dL/dw, f32)
  * gd0[b][p]   = G_0[p] + m[p] * sum_{t=1}^{T} G_t[p]                       (dL/d coarse depth, f32)
  *   d0 [B,H,W], dhist [T,B,H,W] = d_1..d_T (forward history; plane T-1 is not read),
- *   ghist [T+1,B,H,W] in backward order: ghist[s] = G_{T-s}, i.e. ghist[0] = dL/dout and ghist[1..T] is
- *   the history written by cspn_propagate(wT, d0 = ghist[0], ..., history = ghist + plane). */
-int cspn_grad_weights(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+ *   g_T [B,H,W] f32 = G_T = dL/dout (read in place), ghist [T,B,H,W] f32 in backward order: ghist[s] = G_{T-1-s},
+ *   the history written by cspn_propagate_transposed(w, g_T, ..., history = ghist) (NULL when T == 0). */
+int cspn_grad_weights(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
                       float* gw, float* gd0, int d_dtype, int B, int H, int W, int K, int T,
                       cspn_stream_t stream);
 
@@ -173,11 +176,11 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
  * guidance / softmax epilogue there, so dL/dw never goes to HBM:
  *   cspn3_backward_tail    = cspn_grad_weights + cspn3_grad_guidance   (all tensors of one dtype)
  *   cspn_pac_backward_tail = cspn_grad_weights + cspn_pac_grad_guided */
-int cspn3_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
                         const void* guidance, long g_batch_stride, long g_chan_stride, int C, const void* w8,
                         const float* s, void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T,
                         cspn_stream_t stream);
-int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* ghist, const void* sparse,
+int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
                            const void* wk, void* grad_guided, float* gd0, int d_dtype, int w_dtype,
                            int B, int H, int W, int K, int T, cspn_stream_t stream);
 

@@ -86,13 +86,13 @@ def test_fused_tail_equals_unfused_path(sparse, c_oracle):
     gt, d0 = dev(g), dev(d)[:, 0].contiguous()
     w8, S, _ = F.cspn3_prepare(gt, want_s=True)
     _, hist = F.propagate(w8, d0, sp, 3, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True)
-    ghist = F._reverse_sweep(w8, 3, T, sp, cot, None)
-    gw, gd0_ref = F._grad_weights(w8, 3, T, d0, hist, sp, ghist)
+    g_T, ghist = F._reverse_sweep(w8, 3, T, sp, cot, None)
+    gw, gd0_ref = F._grad_weights(w8, 3, T, d0, hist, sp, g_T, ghist)
     L, P, st = F._lib.lib(), F._p, F._stream(gt.device)
     gg_ref, gg = torch.empty_like(gt), torch.full_like(gt, float("nan"))
     gd0 = torch.empty_like(gd0_ref)
     assert L.cspn3_grad_guidance(P(gt), 0, gt.stride(0), gt.stride(1), 12, P(w8), 0, P(S), P(gw), P(gg_ref), B, H, W, st)
-    assert L.cspn3_backward_tail(P(d0), P(hist), P(ghist), P(sp), P(gt), gt.stride(0), gt.stride(1), 12, P(w8), P(S),
+    assert L.cspn3_backward_tail(P(d0), P(hist), P(g_T), P(ghist), P(sp), P(gt), gt.stride(0), gt.stride(1), 12, P(w8), P(S),
                                  P(gg), P(gd0), 0, B, H, W, T, st)
     torch.cuda.synchronize()
     assert not torch.isnan(gg).any()                      # every element written (zero-fill of border targets)
@@ -103,12 +103,12 @@ def test_fused_tail_equals_unfused_path(sparse, c_oracle):
         gd = dev(c_oracle.hash_normal(43, 1, (B, K * K - 1, H, W)))
         wk, _ = F.pac_prepare(gd)
         _, hist = F.propagate(wk, d0, sp, K, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True)
-        ghist = F._reverse_sweep(wk, K, T, sp, cot, None)
-        gw, gx_ref = F._grad_weights(wk, K, T, d0, hist, sp, ghist)
+        g_T, ghist = F._reverse_sweep(wk, K, T, sp, cot, None)
+        gw, gx_ref = F._grad_weights(wk, K, T, d0, hist, sp, g_T, ghist)
         ref, out = torch.empty_like(gd), torch.full_like(gd, float("nan"))
         gx = torch.empty_like(gx_ref)
         assert L.cspn_pac_grad_guided(P(wk), 0, P(gw), P(ref), 0, B, H, W, K, st)
-        assert L.cspn_pac_backward_tail(P(d0), P(hist), P(ghist), P(sp), P(wk), P(out), P(gx), 0, 0, B, H, W, K, T, st)
+        assert L.cspn_pac_backward_tail(P(d0), P(hist), P(g_T), P(ghist), P(sp), P(wk), P(out), P(gx), 0, 0, B, H, W, K, T, st)
         torch.cuda.synchronize()
         assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
         assert torch.allclose(gx, gx_ref, rtol=1e-5, atol=1e-6)
