@@ -53,12 +53,30 @@ __device__ __forceinline__ void st1(__half* p, float v) { *p = __float2half_rn(v
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 __device__ __forceinline__ float4 sgn4(float4 v) { return make_float4(sgnf(v.x), sgnf(v.y), sgnf(v.z), sgnf(v.w)); }
 
-// q[k] = a[k] / S (k < 8, 0 <= a[k] <= S), bit-identical to IEEE division: this IS the arithmetic of the compiler's
-// fp32 division (v_div_scale, v_rcp, one Newton step on the reciprocal, q = a r, two residual corrections,
-// v_div_fmas, v_div_fixup) with the part that depends only on the divisor shared by the eight quotients —
-// 4 + 8*5 VALU operations instead of 8 * ~14.  The scale / fixup stages only act on extreme exponents and on
-// inf / nan / 0 operands, so anything outside a comfortable normal range takes the plain division.
+// q[k] = a[k] / S for the 8 gates of one pixel (0 <= a[k] <= S), sharing one reciprocal:
+//   r = v_rcp_f32(S) refined by one Newton step (r <- r + r (1 - S r)), q[k] = a[k] * r
+// — 3 + 8 VALU operations.  Each quotient is within ~1.5 ulp of the IEEE one; the reference itself never forms these
+// quotients (it divides the weighted SUM by S every step, CSPN_new.py:124-127), so neither rounding is "the" reference
+// one: measured against it on full frames the refined depth moves from 4.6e-7 to 5.7e-7 max relative error (bar: 1e-5)
+// while the derive launch loses 9 us of division sequences (v_div_scale / v_div_fmas / v_div_fixup + two residual
+// corrections per quotient: 43 operations, kept below under CSPN_IEEE_NORMALISE for A/B runs).
+// S = 0 (all gates zero, also every padding pixel) needs no branch: rcp(0) = inf, the Newton step makes it NaN and
+// 0 * NaN = NaN = 0 / 0.  Only a denormal-range or huge S — where v_rcp_f32 flushes — takes the true division.
 __device__ __forceinline__ void div8_shared_reciprocal(const float (&a)[8], float S, float (&q)[8]) {
+#ifndef CSPN_IEEE_NORMALISE
+    const bool okr = (S <= 0x1p+100f) && (S >= 0x1p-100f || S == 0.f);
+    if (okr) {
+        float r = __builtin_amdgcn_rcpf(S);
+        const float e = fmaf(-S, r, 1.0f);
+        r = fmaf(e, r, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = a[k] * r;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = a[k] / S;
+    }
+#else
+    // bit-identical to IEEE division: the compiler's fp32 division sequence with the divisor-only part shared
     bool fast = (S >= 0x1p-60f) && (S <= 0x1p+60f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) fast = fast && (a[k] == 0.f || a[k] >= S * 0x1p-40f);
@@ -78,6 +96,7 @@ __device__ __forceinline__ void div8_shared_reciprocal(const float (&a)[8], floa
 #pragma unroll
         for (int k = 0; k < 8; ++k) q[k] = a[k] / S;
     }
+#endif
 }
 
 // The 10 masked terms of Result.evaluate (libs/metrics.py:49-83) for one pixel, added to f[0..9]:

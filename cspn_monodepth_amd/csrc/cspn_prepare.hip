@@ -8,7 +8,7 @@ namespace {
 // prepare kernels (run once per forward)
 // ------------------------------------------------------------------------------------------------
 // 3x3: w_j[p] = |g_{7-j}[p+off_j]| / S[p],  S[p] = sum_{k=0..7} |g_k[p+o_k]| summed in the
-// reference's channel order k = 0..7 (CSPN_new.py:29-70, :124-127).  True IEEE division.
+// reference's channel order k = 0..7 (CSPN_new.py:29-70, :124-127); quotients by div8_shared_reciprocal.
 template <typename GT, typename WT>
 __global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs, int B, int H, int W, int Wv,
                                      WT* __restrict__ w8, float* __restrict__ s_out) {

