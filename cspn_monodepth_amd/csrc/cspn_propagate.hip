@@ -311,11 +311,9 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     DT* __restrict__ dout = a.d_out ? static_cast<DT*>(a.d_out) + (size_t)b * HW : nullptr;
     DT* __restrict__ hist = a.hist ? static_cast<DT*>(a.hist) + (size_t)b * HW : nullptr;
 
-    float mf[10];
-    if (SCORE) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) mf[k] = 0.f;
-    }
+    // SCORE: the final quads are kept and scored AFTER the step loop, when the weight and window registers are dead —
+    // ten accumulators live across the loop cost the 64-VGPR instance spills and several us.
+    float4 scored_q[SCORE ? NQ : 1];
     for (int s = 1; s <= a.S; ++s) {
         const bool last = (s == a.S);
         if (active) {
@@ -407,16 +405,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                         const float4 uv = make_float4(u[0], u[1], u[2], u[3]);
                         if (hist) st4(hist + (size_t)(s - 1) * plane + off, uv);
                         else if (last) st4(dout + off, uv);
-                        if (SCORE && last) {
-                            const float4 tg = ld4(static_cast<const DT*>(a.target) + (size_t)b * HW + off);
-                            const float t4[4] = {tg.x, tg.y, tg.z, tg.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float o = u[e];
-                                if (sizeof(DT) == 2) o = __half2float(__float2half_rn(o));   // score the stored value
-                                metric_terms(o, t4[e], mf);
-                            }
-                        }
+                        if (SCORE && last) scored_q[SCORE ? i : 0] = uv;
                     }
                 }
             }
@@ -427,6 +416,25 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         }
     }
     if (SCORE) {
+        float mf[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) mf[k] = 0.f;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if ((interior >> i) & 1u) {
+                    const float4 tg = ld4(static_cast<const DT*>(a.target) + (size_t)b * HW + (size_t)(yq0 + i) * W + xq);
+                    const float t4[4] = {tg.x, tg.y, tg.z, tg.w};
+                    const float o4[4] = {scored_q[i].x, scored_q[i].y, scored_q[i].z, scored_q[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float o = o4[e];
+                        if (sizeof(DT) == 2) o = __half2float(__float2half_rn(o));   // score the stored value
+                        metric_terms(o, t4[e], mf);
+                    }
+                }
+            }
+        }
         // fp32 wave reduction (<= 256 pixels per wave), fp64 across the waves, 10 atomics per workgroup
         float* part = lds + (size_t)2 * a.dr * a.ls + (size_t)(BLEND == CSPN_BLEND_SPARSE ? 2 : (BLEND ? 1 : 0)) * a.wr * 4 * a.wq;
         const int wave = tid >> 6;
