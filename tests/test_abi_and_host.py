@@ -81,3 +81,28 @@ def test_shard_bounds_and_finalize():
     fin = ev.finalize_metrics(orc.metric_sums(z["pred"], z["target"]))
     for k, v in zip(ev.METRIC_NAMES, z["metrics"]):
         assert np.isclose(fin[k], v, rtol=2e-6), k
+
+
+def test_widening_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation of the PAC-conv / un-pooling entries happens on the host before any launch: a failing call
+    returns 0 and leaves a message in cspn_last_error() (the In-Place ABN convention the header adopts)."""
+    L = _lib.lib()
+    G = _lib.cspn_conv_geometry
+    err = lambda: L.cspn_last_error().decode()                                     # noqa: E731
+    ok_geom = G(3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0)
+    one = ctypes.c_void_p(16)                                                      # never dereferenced: validation fails first
+    assert L.cspn_pac_conv2d(one, one, one, _lib.CSPN_F32, 1, 3, 2, 8, 8, ctypes.byref(ok_geom), None) == 0
+    assert "Incompatible input and kernel sizes" in err()                          # kernel_ch must be 1 or C (pac.py:77-78)
+    assert L.cspn_pac_conv2d(one, one, one, 7, 1, 3, 1, 8, 8, ctypes.byref(ok_geom), None) == 0 and "dtype" in err()
+    assert L.cspn_pac_conv2d(None, one, one, _lib.CSPN_F32, 1, 3, 1, 8, 8, ctypes.byref(ok_geom), None) == 0 and "null" in err()
+    assert L.cspn_pac_conv2d(one, one, one, _lib.CSPN_F32, 1, 3, 1, 8, 8, None, None) == 0 and "geom" in err()
+    big = G(9, 9, 1, 1, 0, 0, 1, 1, 0, 0, 0)                                       # window larger than the padded input
+    assert L.cspn_pac_conv2d(one, one, one, _lib.CSPN_F32, 1, 1, 1, 4, 4, ctypes.byref(big), None) == 0 and "empty output" in err()
+    tr = G(3, 3, 2, 2, 1, 1, 1, 1, 1, 1, 1)                                        # transposed geometry is nd2col-only
+    assert L.cspn_pac_conv2d_grad_input(one, one, one, _lib.CSPN_F32, 1, 1, 1, 4, 4, ctypes.byref(tr), None) == 0
+    assert "nd2col only" in err()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    assert L.cspn_pac_out_size(6, 7, ctypes.byref(tr), ctypes.byref(ho), ctypes.byref(wo)) == 1 and (ho.value, wo.value) == (12, 14)
+    assert L.cspn_unpool2d(one, one, _lib.CSPN_F32, 4, 5, 6, 2, 11, 12, None) == 0 and "must lie in" in err()   # oH > 2*H
+    assert L.cspn_unpool2d(one, one, _lib.CSPN_F32, 4, 5, 6, 0, 5, 6, None) == 0 and "scale" in err()
+    assert L.cspn_unpool2d_backward(one, None, _lib.CSPN_F32, 4, 5, 6, 2, 10, 12, None) == 0 and "null" in err()
