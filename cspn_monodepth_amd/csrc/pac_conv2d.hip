@@ -288,6 +288,99 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, tiled, any geometry
+// Strided / dilated / non-square windows: same 64 x 16 output tile, the input patch it touches —
+// ((64-1) sw + (kw-1) dw + 1) x ((16-1) sh + (kh-1) dh + 1) — staged in dynamic LDS for `cb` channels at a time and the
+// taps read back as scalar ds_read_b32 (the window is not contiguous).  Thread t owns column x = t % 64 on the four
+// rows (t / 64) + 4 e: a wavefront reads 64 consecutive patch columns (stride sw), which is bank-conflict free for
+// sw = 1 — the quad-per-thread mapping of the other kernels puts 64 lanes on 8 banks here (measured 2.4x slower).
+// The price is 4-byte kernel loads and output stores (coalesced: one 256-byte row segment per wavefront).
+template <typename T, bool SHARED>
+__global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restrict__ in, const T* __restrict__ kern,
+                                                                T* __restrict__ out, ConvArgs a, int tiles_x, int RW,
+                                                                int RH, int cb) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];       // [cb][RH * RW]
+    const int tid = blockIdx.x;
+    const int ty = tid / tiles_x, tx = tid - ty * tiles_x;
+    const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    const int x = tx0 + lx;
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const int psz = RH * RW, ntap = a.kh * a.kw;
+    const int gy0 = ty0 * a.sh - a.ph, gx0 = tx0 * a.sw - a.pw;          // input coordinates of patch element (0,0)
+    bool live[4];
+    size_t opix[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int y = ty0 + ly0 + 4 * e;
+        live[e] = x < a.Wo && y < a.Ho;
+        opix[e] = (size_t)(live[e] ? y : 0) * a.Wo + (live[e] ? x : 0);
+    }
+    const int step_ry = 256 / RW, step_rx = 256 - step_ry * RW;         // uniform: one division per workgroup
+    const int t_ry = threadIdx.x / RW, t_rx = threadIdx.x - t_ry * RW;   // one division per thread
+    for (int c = c_begin; c < c_end; c += cb) {
+        const int nc = min(cb, c_end - c);
+        __syncthreads();
+        // patch element idx = threadIdx.x + 256 n -> (ry, rx), advanced incrementally: integer divisions by the runtime
+        // patch width per element made this kernel VALU-bound (6.6 k VALU instructions per wavefront)
+        {
+            int ry = t_ry, rx = t_rx;
+            for (int idx = threadIdx.x; idx < psz; idx += 256) {
+                const int yi = gy0 + ry, xi = gx0 + rx;
+                const bool ok = (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
+                const size_t goff = (size_t)(ok ? yi : 0) * a.W + (ok ? xi : 0);
+                for (int cc = 0; cc < nc; ++cc)
+                    patch[cc * psz + idx] = ok ? ld1(in + ((size_t)b * a.C + c + cc) * iplane + goff) : 0.f;
+                rx += step_rx; ry += step_ry;
+                if (rx >= RW) { rx -= RW; ++ry; }
+            }
+        }
+        __syncthreads();
+        float acc[CC][4];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
+        const int base0 = ly0 * a.sh * RW + lx * a.sw, estep = 4 * a.sh * RW;
+        int ti = 0, tj = 0;
+#pragma unroll 2
+        for (int tap = 0; tap < ntap; ++tap) {
+            const int base = base0 + ti * a.dh * RW + tj * a.dw;
+            if (++tj == a.kw) { tj = 0; ++ti; }
+            float kv[4];
+            if constexpr (SHARED) {
+                const T* kp = kern + ((size_t)b * ntap + tap) * oplane;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kv[e] = live[e] ? ld1(kp + opix[e]) : 0.f;
+            }
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                if (cc < nc) {
+                    if constexpr (!SHARED) {
+                        const T* kp = kern + (((size_t)b * a.C + c + cc) * ntap + tap) * oplane;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) kv[e] = live[e] ? ld1(kp + opix[e]) : 0.f;
+                    }
+                    const float* pp = patch + cc * psz + base;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(kv[e], pp[e * estep], acc[cc][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (cc < nc) {
+                T* op = out + ((size_t)b * a.C + c + cc) * oplane;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (live[e]) st1(op + opix[e], acc[cc][e]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dL/dkernel
 // thread = (output quad, tap); blockIdx.y = tap.  grad_kernel[b,c|0,i,j,y,x] = (sum_c) g[b,c,y,x] * in0[b,c,...]
 template <typename T, bool VEC, bool SHARED>
@@ -745,13 +838,35 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
         T* o = static_cast<T*>(out);
         return launch_tiled_k<T, false>(i, k, o, a, a.vec, st);
     }
-    const int gx = ceil_div(a.Ho * a.WQ, 256);
-    a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
-    const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
     const T* i = static_cast<const T*>(in);
     const T* k = static_cast<const T*>(kern);
     T* o = static_cast<T*>(out);
     const bool shared = a.CK == 1;
+    if (!a.force_scalar && a.sh == 1 && a.sw == 1 && (size_t)a.H * a.W < ((size_t)1 << 31)) {
+        // other unit-stride geometries (dilation, non-square or even windows): LDS-tiled when the input patch of a 64 x 16
+        // output tile fits 64 KiB for at least one channel.  Strided windows stay on the scalar kernel: their patches are
+        // stride^2 larger per output and the tiled form measured slower (87 vs 77 us at stride 2).
+        const long RWl = ((long)(TILE_W - 1) * a.sw + (long)(a.kw - 1) * a.dw + 1 + 3) & ~3L;
+        const long RHl = (long)(TILE_H - 1) * a.sh + (long)(a.kh - 1) * a.dh + 1;
+        const long psz = RWl * RHl;
+        int cb = (int)std::min<long>(CC, (64 * 1024 / 4) / std::max(psz, 1L));
+        cb = std::min(cb, a.C);
+        if (cb >= 1) {
+            const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+            const size_t want = 1024, have = (size_t)tiles * a.B;
+            int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, cb));
+            a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
+            const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
+            const size_t lds = (size_t)cb * psz * sizeof(float);
+            if (shared) pac_conv2d_fwd_tiled_any<T, true><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else pac_conv2d_fwd_tiled_any<T, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
+    const int gx = ceil_div(a.Ho * a.WQ, 256);
+    a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
+    const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
     if (a.vec && shared) pac_conv2d_fwd<T, true, true><<<grid, block, 0, st>>>(i, k, o, a);
     else if (a.vec) pac_conv2d_fwd<T, true, false><<<grid, block, 0, st>>>(i, k, o, a);
     else if (shared) pac_conv2d_fwd<T, false, true><<<grid, block, 0, st>>>(i, k, o, a);

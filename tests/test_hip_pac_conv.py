@@ -147,6 +147,31 @@ def test_fuzz_tiled_geometry_both_kernels(seed, monkeypatch):
         assert nmax(gk, wgk) <= tol, (tag, scalar)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed, monkeypatch):
+    """Unit stride with dilation / non-square / even windows takes the any-geometry LDS-tiled forward; compare it and the
+    scalar kernel (CSPN_PAC_SCALAR=1) with the oracle on multi-tile frames."""
+    rng = np.random.default_rng(3000 + seed)
+    k = (int(rng.integers(1, 6)), int(rng.integers(1, 6)))
+    d = (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+    if k[0] == k[1] and k[0] in (3, 5, 7) and d == (1, 1):
+        d = (2, 1)
+    p = (int(rng.integers(0, 6)), int(rng.integers(0, 6)))
+    H = int(rng.integers(max(1, d[0] * (k[0] - 1) + 1 - 2 * p[0]), 50))
+    W = int(rng.integers(max(1, d[1] * (k[1] - 1) + 1 - 2 * p[1]), 180))
+    B, C = int(rng.integers(1, 3)), int(rng.integers(1, 10))
+    CK = C if seed % 2 else 1
+    Ho, Wo = porc.out_size((H, W), k, 1, p, d)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kern = rng.standard_normal((B, CK, k[0], k[1], Ho, Wo)).astype(np.float32)
+    want = porc.pac_conv2d_forward(x, kern, k, 1, p, d, dtype=np.float64)
+    for scalar in ("0", "1"):
+        monkeypatch.setenv("CSPN_PAC_SCALAR", scalar)
+        with torch.no_grad():
+            out = pac.conv2d(dev(x), dev(kern), k, 1, p, d).cpu().numpy()
+        assert nmax(out, want) <= TOL, (B, C, CK, H, W, k, p, d, scalar)
+
+
 def test_padding_zero_times_nonfinite_kernel_is_nan_like_unfold():
     # F.unfold gives 0 in the padding and the reference multiplies it by the kernel: 0 * inf = NaN (pac.py:89-92)
     x = np.ones((1, 1, 4, 4), np.float32)
