@@ -161,6 +161,23 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, CSPN_DPP_BOUND_CTRL));
 }
 
+// Sum of v over the 64 lanes of a wavefront, valid in lane 63.  VALU only (DPP row shifts + the gfx9 row broadcasts):
+// the __shfl_down ladder is 6 ds_bpermute_b32 per value and the LDS crossbar became the cost of the fused metrics
+// reduction (10 values x 16 waves per workgroup).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_step(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add_step<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add_step<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add_step<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add_step<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16 holds its row sum
+    v = dpp_add_step<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add_step<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront sum
+    return v;
+}
+
 // All NT taps of the quad starting at pixel p (p % 4 == 0) of one image's tap volume -> out[NT][4] (fp32).
 template <int NT>
 __device__ __forceinline__ void load_taps_quad(const float* img, size_t p, size_t HW, bool ok, float (&out)[NT][4]) {

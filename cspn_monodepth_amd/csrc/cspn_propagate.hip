@@ -314,8 +314,15 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     // SCORE: the final quads are kept and scored AFTER the step loop, when the weight and window registers are dead —
     // ten accumulators live across the loop cost the 64-VGPR instance spills and several us.
     float4 scored_q[SCORE ? NQ : 1];
+    float4 scored_t[SCORE ? NQ : 1];     // the target quads, requested at the top of the last step: their latency hides behind it
     for (int s = 1; s <= a.S; ++s) {
         const bool last = (s == a.S);
+        if (SCORE && last && active) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                if ((interior >> i) & 1u)
+                    scored_t[SCORE ? i : 0] = ld4(static_cast<const DT*>(a.target) + (size_t)b * HW + (size_t)(yq0 + i) * W + xq);
+        }
         if (active) {
             // Window fetch.  One aligned ds_read_b128 per row gives the thread's own 4 pixels; the R pixels
             // to the left / right are the neighbouring lanes' quads, taken with DPP wave shifts (no LDS
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 if ((interior >> i) & 1u) {
-                    const float4 tg = ld4(static_cast<const DT*>(a.target) + (size_t)b * HW + (size_t)(yq0 + i) * W + xq);
+                    const float4 tg = scored_t[i];
                     const float t4[4] = {tg.x, tg.y, tg.z, tg.w};
                     const float o4[4] = {scored_q[i].x, scored_q[i].y, scored_q[i].z, scored_q[i].w};
 #pragma unroll
@@ -440,9 +447,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         const int wave = tid >> 6;
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            float v = mf[k];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if (lane == 0) part[wave * 10 + k] = v;
+            const float v = wave_sum_to_lane63(mf[k]);
+            if (lane == 63) part[wave * 10 + k] = v;
         }
         __syncthreads();
         if (tid < 10) {
