@@ -286,6 +286,12 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
         }
         const float4 Sv = ld4(a.S + off);
         const float S4[4] = {Sv.x, Sv.y, Sv.z, Sv.w};
+        float rS[4];          // 1/S by the forward's recipe (rcp + one Newton step): 4 reciprocals instead of 32 divisions
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r = __builtin_amdgcn_rcpf(S4[e]);
+            rS[e] = fmaf(fmaf(-S4[e], r, 1.0f), r, r);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int lin = j < 4 ? j : j + 1;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
             const int ty = y + dy;
             float gA[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gA[e] = (acc[j][e] - dot[e]) / S4[e];
+            for (int e = 0; e < 4; ++e) gA[e] = (acc[j][e] - dot[e]) * rS[e];
             // Scatter gA_j[p] to p + off_j as ALIGNED quads of the target row ty: the target quad [x, x+4) takes
             // source columns [x-dx, x+4-dx), i.e. three own values and one from the neighbouring lane (DPP).
             // Where that neighbour sits in another wave (lane 0 / 63 inside a row) the element is written by its

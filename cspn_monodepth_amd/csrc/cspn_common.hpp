@@ -178,6 +178,25 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// The same for fp64 (the standalone metrics kernel accumulates arbitrarily many pixels per thread): DPP moves the two
+// 32-bit halves, the add is a plain v_add_f64.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return x + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    v = dpp_add_step<0x111, 0xf>(v);
+    v = dpp_add_step<0x112, 0xf>(v);
+    v = dpp_add_step<0x114, 0xf>(v);
+    v = dpp_add_step<0x118, 0xf>(v);
+    v = dpp_add_step<0x142, 0xa>(v);
+    v = dpp_add_step<0x143, 0xc>(v);
+    return v;
+}
+
 // All NT taps of the quad starting at pixel p (p % 4 == 0) of one image's tap volume -> out[NT][4] (fp32).
 template <int NT>
 __device__ __forceinline__ void load_taps_quad(const float* img, size_t p, size_t HW, bool ok, float (&out)[NT][4]) {

@@ -42,14 +42,13 @@ __global__ __launch_bounds__(1024) void cspn_metrics_kernel(const DT* __restrict
     double s[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) s[k] = (double)f[k];
-    // wave64 shuffle reduction -> LDS -> one atomic per block and quantity (10 per block)
+    // wavefront sum by DPP (no LDS crossbar) -> LDS -> one atomic per block and quantity (10 per block)
     __shared__ double part[16][10];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-        double v = s[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) part[wave][k] = v;
+        const double v = wave_sum_to_lane63(s[k]);
+        if (lane == 63) part[wave][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < 10) {
