@@ -13,7 +13,7 @@ for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum T
     ptag=$( [ "$plan" = default ] && echo fused || echo step )
     extra=""; [ "$plan" = default ] || extra="--plan $plan"
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${WL}_${ptag}_$tag -o pmc -- \
-      python $R/bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-train-leg --no-per-step-leg --cold-sets 0 --prewarm-s 0 $extra > $O/${WL}_${ptag}_$tag.log 2>&1
+      python $R/bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-train-leg --no-per-step-leg --cold-sets 0 --prewarm-s 0 --graph off $extra > $O/${WL}_${ptag}_$tag.log 2>&1
   done
 done
 cd $R

@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/$tag -o pmc -- \
-    python $R/bench.py $EXTRA --steps 6 --warmup 2 --no-cpu-baseline --prewarm-s 0 --cold-sets 0 --no-per-step-leg --no-train-leg > $O/$tag.log 2>&1
+    python $R/bench.py $EXTRA --steps 6 --warmup 2 --no-cpu-baseline --prewarm-s 0 --cold-sets 0 --no-per-step-leg --no-train-leg --graph off > $O/$tag.log 2>&1
 done
 cd $R
 python - <<PY
