@@ -223,6 +223,31 @@ def test_linearity_and_adjointness_at_full_size():
     assert torch.equal(o2, 2.0 * out.detach())              # scaling by 2 is exact in binary floating point
 
 
+@pytest.mark.parametrize("C,CK,K,s,p,d", [(16, 1, 5, 1, 2, 1), (8, 8, 3, 1, 1, 1), (6, 1, 7, 1, 3, 1), (8, 1, 3, 2, 1, 1),
+                                          (8, 1, 3, 1, 2, 2), (5, 5, (3, 2), 1, (1, 0), (1, 3))])
+def test_full_frame_against_the_unfold_formulation(C, CK, K, s, p, d):
+    """NYU-size frames, many tiles and channel batches: forward and both gradients against the reference's own
+    formulation (F.unfold * kernel, summed — pac.py:89-92 / :130-140) evaluated with stock torch ops and autograd on the
+    same GPU in fp64.  An independent implementation, not the oracle: it checks scale, tiling seams and channel batching."""
+    B, H, W = 2, 228, 304
+    torch.manual_seed(11)
+    kh, kw = (K, K) if isinstance(K, int) else K
+    Ho, Wo = pac.output_size((H, W), K, s, p, d)
+    x = torch.randn(B, C, H, W, device=DEV)
+    k = torch.randn(B, CK, kh, kw, Ho, Wo, device=DEV) * 0.3
+    g = torch.randn(B, C, Ho, Wo, device=DEV)
+    xr, kr = x.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    out = pac.conv2d(xr, kr, K, s, p, d)
+    out.backward(g)
+    x64, k64 = x.double().requires_grad_(True), k.double().requires_grad_(True)
+    cols = torch.nn.functional.unfold(x64, (kh, kw), d, p, s).view(B, C, kh, kw, Ho, Wo)
+    ref = (cols * k64).sum(dim=(2, 3))
+    ref.backward(g.double())
+    for got, want in ((out, ref), (xr.grad, x64.grad), (kr.grad, k64.grad)):
+        err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
+        assert err <= TOL, (C, CK, K, s, p, d, err)
+
+
 def test_only_needed_gradients_are_computed():
     x = torch.randn(1, 2, 8, 8, device=DEV)
     k = torch.randn(1, 1, 3, 3, 8, 8, device=DEV, requires_grad=True)
