@@ -206,10 +206,14 @@ def main():
                 w_, _ = F.pac_prepare(g)
             sp_ = None if s is None else s[:, 0].contiguous()
             plan = F.autotune_plan(w_, d[:, 0].contiguous(), sp_, K, T,
-                                   F.BLEND_SPARSE if s is not None else F.BLEND_NONE)
+                                   F.BLEND_SPARSE if s is not None else F.BLEND_NONE, guidance=g if K == 3 else None,
+                                   score=None if (args.no_metrics or K != 3) else (
+                                       target[:, 0].contiguous(), pkg.evaluation.new_accumulator(device)))
             del w_
         module.plan = plan
-    eff_plan = F.resolve_plan(K, B_local, wl["H"], wl["W"], T, False, plan)
+    w_torch_dtype = torch.float16 if wl["dtype"] == "f16" else torch.float32
+    eff_plan = F.resolve_plan(K, B_local, wl["H"], wl["W"], T, False,
+                              plan if K == 3 else F.dtype_default_plan(K, w_torch_dtype, plan))
     sums = pkg.evaluation.new_accumulator(device)
 
     if K == 3:

@@ -545,21 +545,26 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
 //   * tile width = W split into n equal parts (rounded up to whole quads), tile height = every row the
 //     workgroup can own, evened out over the image; the (n, height) pair with the fewest total
 //     weight-region pixels (tiles x (tile + halo)) wins, wider tile on ties.
-void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan* p) {
+// Fields the caller pins (steps_per_launch, quads_per_thread, threads > 0 in `user`) are taken as given and the tile
+// search runs for THEM, so a partial plan such as {S = 4, NQ = 3, 256 threads} still gets the cheapest tiling.
+void default_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {
     (void)keep_history;
     const int R = K / 2;
     p->force_scalar = 0;
-    p->quads_per_thread = 1;
+    p->quads_per_thread = (user && user->quads_per_thread > 0) ? user->quads_per_thread : 1;
     p->tile_w = 0;
     p->tile_h = 0;
     int S0 = (K == 3) ? 8 : (K == 5 ? 3 : 2);
+    const bool s_pinned = user && user->steps_per_launch > 0;
+    if (s_pinned) S0 = user->steps_per_launch;
     if (T < 1) T = 1;
     if (S0 > T) S0 = T;
-    S0 = ceil_div(T, ceil_div(T, S0));               // balance the launches (T=24, S0=8 -> 3 x 8)
+    if (!s_pinned) S0 = ceil_div(T, ceil_div(T, S0));   // balance the launches (T=24, S0=8 -> 3 x 8)
     // Largest workgroup first (least halo); small batches step down to 512 threads when the launch would leave
     // most CUs without a tile (B=3 at 304x228 with 1024-thread tiles occupies 90 of the 256 CUs).  Going further
     // down (256 threads) costs more in halo work than it gains in occupancy (plan sweeps at B=1..3).
-    const int thread_opts[3] = {(K == 3) ? 1024 : 256, (K == 3) ? 512 : 0, 0};
+    int thread_opts[3] = {(K == 3) ? 1024 : 256, (K == 3) ? 512 : 0, 0};
+    if (user && user->threads > 0) { thread_opts[0] = user->threads; thread_opts[1] = 0; }
     for (int ti = 0; ti < 3; ++ti) {
         const int threads = thread_opts[ti];
         if (!threads) break;
@@ -597,7 +602,7 @@ void default_plan(int K, int B, int H, int W, int T, int keep_history, cspn_plan
 }
 
 void resolve_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {
-    default_plan(K, B, H, W, T, keep_history, p);
+    default_plan(K, B, H, W, T, keep_history, user, p);
     if (user) {
         if (user->steps_per_launch > 0) p->steps_per_launch = user->steps_per_launch;
         if (user->tile_w > 0) p->tile_w = user->tile_w;
