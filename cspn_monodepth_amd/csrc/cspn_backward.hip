@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
     // Software-pipelined stream over the histories: the loads of UNR steps (G quad, 2R+1 row quads, and the
     // strip-end lanes' scalar halo patches) are all issued before the first one is consumed; otherwise every
     // step (and every patch load) is a serialised HBM/L2 round trip and the pass is latency-bound.
-    constexpr int UNR = (K == 3) ? 4 : (K == 5 ? 2 : 1);
+#ifndef CSPN_TAIL_UNR3
+#define CSPN_TAIL_UNR3 3       // 124 VGPRs -> 4 waves/SIMD; 4 steps in flight need 146 (3 waves) and measured 2.5 % slower
+#endif
+    constexpr int UNR = (K == 3) ? CSPN_TAIL_UNR3 : (K == 5 ? 2 : 1);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t0 = 0; t0 < T; t0 += UNR) {
         float4 Gq[UNR], midq[UNR][2 * R + 1];
