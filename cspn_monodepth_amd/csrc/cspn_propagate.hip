@@ -544,7 +544,7 @@ bool make_geometry(int K, int B, int H, int W, int S, int tw, int th, int nq, in
 //     workgroups per CU overlap one tile's weight stream with the other's LDS steps;
 //   * tile width = W split into n equal parts (rounded up to whole quads), tile height = every row the
 //     workgroup can own, evened out over the image; the (n, height) pair with the fewest total
-//     weight-region pixels (tiles x (tile + halo)) wins, wider tile on ties.
+//     weight-region cache lines (tiles x region rows x lines per row) wins, wider tile on ties.
 // Fields the caller pins (steps_per_launch, quads_per_thread, threads > 0 in `user`) are taken as given and the tile
 // search runs for THEM, so a partial plan such as {S = 4, NQ = 3, 256 threads} still gets the cheapest tiling.
 void default_plan(int K, int B, int H, int W, int T, int keep_history, const cspn_plan* user, cspn_plan* p) {
@@ -583,7 +583,12 @@ void default_plan(int K, int B, int H, int W, int T, int keep_history, const csp
                 if (th < 1 || (th < 8 && th < H)) continue;
                 th = ceil_div(H, ceil_div(H, th));   // even out the tile rows
                 const long tiles = (long)ceil_div(W, tw) * ceil_div(H, th);
-                const long cost = tiles * (4L * wq) * (th + 2 * hyw);
+                // region rows x 128-byte lines per row (a 16-byte-aligned row segment of wq quads touches wq/8 + 7/8
+                // lines on average): plain pixel counts favoured narrow tiles whose rows waste most of their last line
+                // (NYU: 52x46 modelled 5 % cheaper than 76x30 but measured 7 % slower with history, 2 % without).  The
+                // 24/48-tap kernels are VALU-bound — their cost follows the pixel count — so the line term is small there
+                // (K = 5, fp16, S = 4 / NQ = 3: the full term picks 76x21, 179 k maps/s, against 190-194 k for 44x38 / 52x33).
+                const long cost = tiles * (long)(wq + (K == 3 ? 7 : 2)) * (th + 2 * hyw);
                 if (best_cost < 0 || cost < best_cost) { best_cost = cost; tw_best = tw; th_best = th; tiles_best = tiles; }
             }
             if (best_cost >= 0 || S == 1) break;
