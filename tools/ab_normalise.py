@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
 """A/B of the weight normalisation arithmetic (developer tool): error vs the goldens and forward time.
-Run once per library build:  CSPN_HIP_LIB=... python tools/ab_normalise.py"""
+
+Build the alternative library next to the default one and run the tool once per build (the flags must be repeated on
+the GPU box, or the content hash differs and the library is rebuilt with the default flags):
+
+    CSPN_HIP_LIB=$PWD/_ab/libcspn_ieee.so CSPN_HIPCC_FLAGS=-DCSPN_IEEE_NORMALISE python -c \
+        "from cspn_monodepth_amd import _lib; _lib.build(force=True)"
+    gpurun -- 'python tools/ab_normalise.py; CSPN_HIPCC_FLAGS=-DCSPN_IEEE_NORMALISE \
+        CSPN_HIP_LIB=$GRAFT_REPO_ROOT/_ab/libcspn_ieee.so python tools/ab_normalise.py'"""
 import os, sys, glob
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
