@@ -153,8 +153,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the forward+backward leg")
     ap.add_argument("--no-per-step-leg", action="store_true", help="skip the S=1 schedule leg (profiling runs)")
-    ap.add_argument("--cold-sets", type=int, default=4,
-                    help="extra leg: rotate over this many input sets (> 256 MiB in total); 0/1 disables it")
+    ap.add_argument("--cold-sets", type=int, default=8,
+                    help="extra leg: rotate over this many input sets (SURVEY.md 8d: >= 8 sets, > 256 MiB in total); 0/1 disables it")
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed steady-state pre-warm-up before the W warm-up steps")
     ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
     args = ap.parse_args()
