@@ -110,15 +110,16 @@ int cspn_propagate(const void* w, int w_dtype, const void* d0, const void* spars
 /* cspn_propagate + cspn_metrics_accumulate in one: the launch that produces d_T also accumulates the depth
  * metrics of its pixels against `target` [B,H,W] (d_dtype) into acc[nslots][10] (see cspn_metrics_accumulate),
  * so the refined batch is not read back by a separate reduction pass.  Inference only (no history), prepared
- * tap volume, K in {3,5}, w_dtype == d_dtype, W % 4 == 0 and 16-byte aligned tensors, a plan with one quad per
- * thread (the built-in plans); returns 0 otherwise and the caller uses the two-call form. */
+ * tap volume, K in {3,5}, w_dtype == d_dtype, W % 4 == 0 and 16-byte aligned tensors, a plan that has a scoring
+ * kernel instance (one quad per thread; also two at 512 threads for K = 3); returns 0 otherwise and the caller
+ * uses the two-call form. */
 int cspn_propagate_scored(const void* w, int w_dtype, const void* d0, const void* sparse, void* out, void* work,
                           int d_dtype, int B, int H, int W, int W_valid, int K, int T, int blend,
                           const void* target, double* acc, int nslots, const cspn_plan* plan, cspn_stream_t stream);
 
-/* 3x3 variant: cspn3_prepare and cspn_propagate in one — every launch derives the normalised
- * weights from the raw guidance (same arithmetic, bit-identical results), so the 8 weight planes are never
- * written to or re-read from HBM.  Arguments as cspn3_prepare (guidance, strides) + cspn_propagate.
+/* 3x3 variant: cspn3_prepare and cspn_propagate in one — the launch itself derives the normalised weights from
+ * the raw guidance (same arithmetic as cspn3_prepare, bit-identical results); no separate prepare pass.
+ * Arguments as cspn3_prepare (guidance, strides) + cspn_propagate.
  * w8_out_or_null: NULL = every launch re-derives the weights (no weight volume at all); a [B,8,H,W] tap volume of
  * g_dtype = the FIRST launch derives the weights and also publishes them there, the following launches stream
  * them (one prepare pass and one read of the volume saved).
