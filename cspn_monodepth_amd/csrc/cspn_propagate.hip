@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     // of the quad, two halfs per VGPR) and feed v_fma_mix_f32 directly: half the weight registers of the fp32
     // form (higher occupancy / more bytes in flight per wave) and no conversion instructions.
     constexpr bool PACKED = std::is_same<WT, __half>::value && WSRC == 0;
+    constexpr bool FOLD = (BLEND == CSPN_BLEND_SPARSE) && !PACKED;   // sparse blend folded into the weight registers
     float wreg[PACKED ? 1 : NQ][PACKED ? 1 : NT][4];
     uint4 wpk[PACKED ? NQ : 1][PACKED ? NT / 2 : 1];
     unsigned in_img = 0, interior = 0;
@@ -264,7 +265,17 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
         if (BLEND && r < wr) {
             const float4 m = ok ? sgn4(ld4(spg + off)) : z4;
             const int qoff = (r * wq + sx) * 4;
-            *reinterpret_cast<float4*>(om_lds + qoff) = make_float4(1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w);
+            if constexpr (FOLD) {
+                // (1-m) u + m d0 with u = sum_j w_j d_j  ==  sum_j ((1-m) w_j) d_j + m d0: 1-m is 0, 1 or 2, so the scaled
+                // weights and every product are exact and the result is bit-identical — the steps then only add m d0
+                const float omq[4] = {1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w};
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wreg[i][j][e] *= omq[e];
+            } else {
+                *reinterpret_cast<float4*>(om_lds + qoff) = make_float4(1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w);
+            }
             if (BLEND == CSPN_BLEND_SPARSE) {
                 const float4 v = ok ? ld4(static_cast<const DT*>(a.d0) + (size_t)b * HW + off) : z4;
                 *reinterpret_cast<float4*>(md_lds + qoff) = make_float4(m.x * v.x, m.y * v.y, m.z * v.z, m.w * v.w);
@@ -384,8 +395,10 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                     float om[4] = {1.f, 1.f, 1.f, 1.f}, md[4] = {0.f, 0.f, 0.f, 0.f};
                     if (BLEND) {
                         const int qoff = ((r0 + i) * wq + sx) * 4;
-                        const float4 o4 = *reinterpret_cast<const float4*>(om_lds + qoff);
-                        om[0] = o4.x; om[1] = o4.y; om[2] = o4.z; om[3] = o4.w;
+                        if constexpr (!FOLD) {
+                            const float4 o4 = *reinterpret_cast<const float4*>(om_lds + qoff);
+                            om[0] = o4.x; om[1] = o4.y; om[2] = o4.z; om[3] = o4.w;
+                        }
                         if (BLEND == CSPN_BLEND_SPARSE) {
                             const float4 m4 = *reinterpret_cast<const float4*>(md_lds + qoff);
                             md[0] = m4.x; md[1] = m4.y; md[2] = m4.z; md[3] = m4.w;
@@ -394,7 +407,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (BLEND == CSPN_BLEND_SPARSE) {
-                            u[e] = om[e] * u[e] + md[e];          // (1-m) u + m d0     CSPN_new.py:90
+                            // (1-m) u + m d0     CSPN_new.py:90 ((1-m) lives in the weights when FOLD)
+                            u[e] = FOLD ? u[e] + md[e] : om[e] * u[e] + md[e];
                             keep[e] = u[e];
                         } else if (BLEND == CSPN_BLEND_PREMASK) {
                             keep[e] = om[e] * u[e];
