@@ -326,6 +326,19 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
     // ten accumulators live across the loop cost the 64-VGPR instance spills and several us.
     float4 scored_q[SCORE ? NQ : 1];
     float4 scored_t[SCORE ? NQ : 1];     // the target quads, requested at the top of the last step: their latency hides behind it
+    // The centre rows of a thread's window are its own previous outputs: they stay in registers from step to step
+    // instead of being read back from LDS (NQ of the NQ + 2R window reads per step: -3 % per forward at config 2;
+    // the step loop is bound by LDS traffic and barrier latency rather than by VALU issue).
+    float own[NQ][4];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            int drow = r0 + i + R;
+            if (NQ > 1) drow = drow < dr ? drow : dr - 1;
+            const v4f mid = *(lds_cv4f_ptr)(cur + drow * ls + cb);
+            own[i][0] = mid.x; own[i][1] = mid.y; own[i][2] = mid.z; own[i][3] = mid.w;
+        }
+    }
     for (int s = 1; s <= a.S; ++s) {
         const bool last = (s == a.S);
         if (SCORE && last && active) {
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                     scored_t[SCORE ? i : 0] = ld4(static_cast<const DT*>(a.target) + (size_t)b * HW + (size_t)(yq0 + i) * W + xq);
         }
         if (active) {
-            // Window fetch.  One aligned ds_read_b128 per row gives the thread's own 4 pixels; the R pixels
+            // Window fetch.  One aligned ds_read_b128 per neighbour row (the thread's own rows are in `own`); the R pixels
             // to the left / right are the neighbouring lanes' quads, taken with DPP wave shifts (no LDS
             // traffic, no bank conflicts).  Only the lanes at the ends of a strip row (and wave lanes 0 / 63)
             // fetch their halo from LDS, in two exec-masked blocks.
@@ -351,8 +364,14 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
             for (int rr = 0; rr < NQ + 2 * R; ++rr) {
                 // volatile: keep this ONE ds_read_b128.  Left alone, the optimiser re-loads overlapping
                 // dword pairs from LDS (bank-conflicted ds_read2_b32) to feed v_pk_fma_f32 operand pairs.
-                const v4f mid = *(lds_cv4f_ptr)(row_ptr(rr));
-                const float m4[4] = {mid.x, mid.y, mid.z, mid.w};
+                float m4[4];
+                if (rr >= R && rr < R + NQ) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) m4[c] = own[rr - R][c];
+                } else {
+                    const v4f mid = *(lds_cv4f_ptr)(row_ptr(rr));
+                    m4[0] = mid.x; m4[1] = mid.y; m4[2] = mid.z; m4[3] = mid.w;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
 #pragma unroll
@@ -421,6 +440,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<K, NQ>::value)) void cspn_prop_
                     if (!last)
                         *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) =
                             make_float4(keep[0], keep[1], keep[2], keep[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) own[i][e] = keep[e];
                     if ((interior >> i) & 1u) {
                         const size_t off = (size_t)(yq0 + i) * W + xq;
                         const float4 uv = make_float4(u[0], u[1], u[2], u[3]);
