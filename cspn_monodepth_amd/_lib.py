@@ -20,7 +20,7 @@ HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include",
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 3          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 4          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -30,7 +30,7 @@ EXPORTS = (
     "cspn_transpose_weights",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
-    "cspn_pac_out_size", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
+    "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
 )
 
 
@@ -120,6 +120,7 @@ def _declare(lib):
     lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, ci, vp]
     geom = ctypes.POINTER(cspn_conv_geometry)
     lib.cspn_pac_out_size.argtypes = [ci, ci, geom, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.cspn_pac_force_generic.argtypes = [ci, ctypes.POINTER(ci)]
     lib.cspn_pac_conv2d.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
     lib.cspn_pac_conv2d_grad_input.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]
     lib.cspn_pac_conv2d_grad_kernel.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, geom, vp]

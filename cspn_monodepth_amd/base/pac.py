@@ -12,6 +12,7 @@ Differences:
   * ``native_impl`` selects between two formulations of the same sum in the reference (identical outputs, golden
     manifest ``branches_max_abs`` = 0); here both values run the one HIP kernel.
   * ``Conv2dFn.backward`` works (the reference's needs the THNN backend removed in torch 1.0).
+  * ``nd2col`` is differentiable (its backward is the fold, run by cspn_pac_conv2d_grad_input).
   * ``nd2col(transposed=True)`` accepts any channel count (the reference's 1x1 ones-kernel trick only C = 1);
     ``use_pyinn_if_possible`` is accepted and ignored (PyINN is a CUDA-only dependency).
   * fp16 tensors accumulate in fp32 and round once (the reference multiplies and sums in half).
@@ -137,18 +138,57 @@ def conv2d(input, kernel, kernel_size, stride=1, padding=0, dilation=1, native_i
     return _forward(input, kernel, _geometry(kernel_size, stride, padding, dilation))
 
 
+class _Nd2colFn(Function):
+    """nd2col with its autograd adjoint (the fold): the reference's nd2col is differentiable through F.unfold /
+    conv_transpose2d / F.pad (pac.py:51-68), and conv2d(native_impl=True) backpropagates through it (pac.py:130-140)."""
+
+    @staticmethod
+    def forward(ctx, input_nd, g):
+        dev = _require_device(input_nd)
+        B, C, H, W = input_nd.shape
+        Ho, Wo = output_size((H, W), (g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw), (g.oph, g.opw), bool(g.transposed))
+        x = input_nd.contiguous()
+        cols = torch.empty((B, C, g.kh, g.kw, Ho, Wo), dtype=x.dtype, device=dev)
+        with _device_guard(dev):
+            ok = _lib.lib().cspn_pac_nd2col(_p(x), _p(cols), _dt(x), B, C, H, W, ctypes.byref(g), _stream(dev))
+        _lib.check(ok, "cspn_pac_nd2col")
+        ctx.geom = g
+        ctx.input_shape = (B, C, H, W)
+        return cols
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_cols):
+        # fold(grad_cols) = the dL/dinput kernel of the op (cspn_pac_conv2d_grad_input) applied to grad_out = 1 and a
+        # per-channel "kernel" = grad_cols: grad_input[q] = sum over the windows covering q of 1 * grad_cols[...].
+        g = ctx.geom
+        B, C, H, W = ctx.input_shape
+        gc = grad_cols.contiguous()
+        Ho, Wo = gc.shape[-2:]
+        ones = torch.ones((B, C, Ho, Wo), dtype=gc.dtype, device=gc.device)
+        if not g.transposed:
+            return _grad_input(ones, gc, (B, C, H, W), _geometry((g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw))), None
+        # transposed (pac.py:51-58): the windows slide with stride 1 over the zero-inserted, padded plane V;
+        # fold into V, then read back the positions the input samples occupy
+        lead = ((g.kh - 1) * g.dh - g.ph, (g.kw - 1) * g.dw - g.pw)
+        Hv = (H - 1) * g.sh + 1 + 2 * lead[0] + g.oph
+        Wv = (W - 1) * g.sw + 1 + 2 * lead[1] + g.opw
+        gv = _grad_input(ones, gc, (B, C, Hv, Wv), _geometry((g.kh, g.kw), 1, 0, (g.dh, g.dw)))
+        return gv[:, :, lead[0]::g.sh, lead[1]::g.sw][:, :, :H, :W].contiguous(), None
+
+
 def nd2col(input_nd, kernel_size, stride=1, padding=0, output_padding=0, dilation=1, transposed=False,
            use_pyinn_if_possible=False):
-    """[B,C,H,W] -> [B,C,kh,kw,Ho,Wo] (pac.py:35-70; 2-D only, as F.unfold).  Not differentiable here."""
-    dev = _require_device(input_nd)
+    """[B,C,H,W] -> [B,C,kh,kw,Ho,Wo] (pac.py:35-70; 2-D only, as F.unfold).  Differentiable (first order): the
+    backward is the fold, run by the op's dL/dinput kernel."""
+    _require_device(input_nd)
     if input_nd.dim() != 4:
         raise ValueError("nd2col: only [B,C,H,W] input is supported (as F.unfold), got %s" % (tuple(input_nd.shape),))
     g = _geometry(kernel_size, stride, padding, dilation, output_padding, transposed)
-    B, C, H, W = input_nd.shape
-    Ho, Wo = output_size((H, W), (g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw), (g.oph, g.opw), transposed)
-    x = input_nd.detach().contiguous()
-    cols = torch.empty((B, C, g.kh, g.kw, Ho, Wo), dtype=x.dtype, device=dev)
-    with _device_guard(dev):
-        ok = _lib.lib().cspn_pac_nd2col(_p(x), _p(cols), _dt(x), B, C, H, W, ctypes.byref(g), _stream(dev))
-    _lib.check(ok, "cspn_pac_nd2col")
-    return cols
+    if torch.is_grad_enabled() and input_nd.requires_grad:
+        return _Nd2colFn.apply(input_nd, g)
+    return _Nd2colFn.forward(_NoCtx(), input_nd.detach(), g)
+
+
+class _NoCtx(object):
+    """ctx stand-in for no-grad calls that skip Function.apply."""

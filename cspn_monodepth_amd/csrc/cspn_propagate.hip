@@ -16,6 +16,8 @@
 // No fast-math: the reference's 0/0 = NaN semantics (CSPN_new.py:127) must survive.
 #include "cspn_common.hpp"
 
+#include <atomic>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -668,14 +670,27 @@ bool has_instance(int K, int nq, int threads) {
     return K == 7 && nq == 1 && threads == 256;
 }
 
+// Launches with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// (kernel instance, device); the granted size is remembered so the hot loop does not repeat the driver call.
+template <auto Kern>
+int ensure_dynamic_lds(size_t bytes) {
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    std::atomic<size_t>& slot = granted[dev & 63];
+    if (slot.load(std::memory_order_acquire) >= bytes) return 1;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    size_t seen = slot.load(std::memory_order_relaxed);
+    while (seen < bytes && !slot.compare_exchange_weak(seen, bytes, std::memory_order_release)) {}
+    return 1;
+}
+
 template <int K, int NQ, int NTHREADS, typename WT, typename DT, int WSRC, int SCORE = 0>
 int launch_fused_blend(const Launch& L, int blend, hipStream_t st) {
 #define CSPN_LAUNCH(BL)                                                                               \
     do {                                                                                              \
-        auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL, WSRC, SCORE>;                        \
-        if (L.lds_bytes > 64 * 1024)                                                                  \
-            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes)); \
+        constexpr auto kern = cspn_prop_fused<K, NQ, NTHREADS, WT, DT, BL, WSRC, SCORE>;              \
+        if (L.lds_bytes > 64 * 1024 && !ensure_dynamic_lds<kern>(L.lds_bytes)) return 0;              \
         hipLaunchKernelGGL(kern, dim3(L.grid), dim3(NTHREADS), L.lds_bytes, st, L.a);                 \
     } while (0)
     switch (blend) {

@@ -9,9 +9,20 @@
 #include "cspn_common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace {
+
+// Process-wide A/B switch: 1 = skip the LDS-tiled kernels and run the generic one-quad-per-thread kernels.  Initialised
+// once from CSPN_PAC_SCALAR=1 in the environment, changed at run time through cspn_pac_force_generic (tests, A/B runs).
+std::atomic<int>& force_generic_flag() {
+    static std::atomic<int> flag{[] {
+        const char* fs = getenv("CSPN_PAC_SCALAR");
+        return (fs && fs[0] == '1') ? 1 : 0;
+    }()};
+    return flag;
+}
 
 struct ConvArgs {
     int B, C, CK, H, W, Ho, Wo, WQ;      // WQ = ceil(Wo / 4) output quads per row
@@ -760,8 +771,7 @@ int make_args(const char* who, int dtype, int B, int C, int CK, int H, int W, co
         return fail("%s: transposed geometry with padding > (k-1)*dilation is not defined (negative pad)", who);
     if (!out_size(H, W, *g, &r.Ho, &r.Wo)) return fail("%s: geometry gives an empty output for input %dx%d", who, H, W);
     r.WQ = ceil_div(r.Wo, 4);
-    const char* fs = getenv("CSPN_PAC_SCALAR");
-    r.force_scalar = fs && fs[0] == '1';
+    r.force_scalar = force_generic_flag().load(std::memory_order_relaxed);
     if ((size_t)r.Ho * r.WQ > (size_t)1 << 30) return fail("%s: plane too large", who);
     *a = r;
     return 1;
@@ -966,6 +976,12 @@ int nd2col_typed(const void* in, void* cols, ConvArgs a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int cspn_pac_force_generic(int on, int* previous_or_null) {
+    const int prev = force_generic_flag().exchange(on ? 1 : 0, std::memory_order_relaxed);
+    if (previous_or_null) *previous_or_null = prev;
+    return 1;
+}
 
 int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int* Wo) {
     if (!geom || !Ho || !Wo) return fail("cspn_pac_out_size: null argument");

@@ -609,51 +609,76 @@ class CSPN3Function(torch.autograd.Function):
 
 
 class PACFunction(torch.autograd.Function):
-    """K x K softmax variant (CSPN_ours.py / pac.py) forward + backward."""
+    """K x K softmax variant (CSPN_ours.py / pac.py) forward + backward.
+
+    x is [B,C,H,W] as the reference documents it (CSPN_ours.py:24-29): pac.conv2d broadcasts the shared [B,1,K,K,H,W]
+    kernel over the channels (pac.py:89-92) and the [B,1,H,W] sparse mask broadcasts in the blend (:51-53), so the C
+    planes are independent recurrences over ONE tap volume.  C = 1 (the depth map, unet_ours.py:333) is the tuned path;
+    C > 1 runs the same launches once per plane against the shared volume (softmax / prepare done once, dL/dguided
+    summed over the planes — the softmax backward is linear in dL/dkernel)."""
 
     @staticmethod
     def forward(ctx, x, guided, sparse_depth, prop_time, plan, state_dtype, valid_w=0):
         B, C, H, W = guided.shape
-        if x.dim() != 4 or x.shape[1] != 1:
-            raise ValueError("x must be [B,1,H,W] (the depth map); got %s" % (tuple(x.shape),))
+        if x.dim() != 4 or x.shape[0] != B or tuple(x.shape[2:]) != (H, W) or x.shape[1] < 1:
+            raise ValueError("x must be [B,C,H,W] matching guided [B,K*K-1,H,W]; got %s and %s" % (
+                tuple(x.shape), tuple(guided.shape)))
+        CX = x.shape[1]
         wk, K = pac_prepare(guided)
         sdt = x.dtype if state_dtype is None else state_dtype
-        d0 = _plane(x, B, H, W, "x").to(sdt)
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         sp = None if sp is None else sp.to(sdt)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         # the dtype-specific built-in plan serves the forward only: the reverse sweep has its own instances
-        out, hist = propagate(wk, d0, sp, K, prop_time, BLEND_SPARSE if sp is not None else BLEND_NONE,
-                              keep_history=need_grad, plan=dtype_default_plan(K, wk.dtype, plan), valid_w=valid_w)
+        fplan = dtype_default_plan(K, wk.dtype, plan)
+        blend = BLEND_SPARSE if sp is not None else BLEND_NONE
+        outs, saved = [], []
+        for c in range(CX):
+            d0 = _plane(x[:, c:c + 1], B, H, W, "x").to(sdt)
+            out, hist = propagate(wk, d0, sp, K, prop_time, blend, keep_history=need_grad, plan=fplan, valid_w=valid_w)
+            outs.append(out)
+            saved += [d0, hist]
         if need_grad:
-            ctx.save_for_backward(wk, d0, sp, hist)
+            ctx.save_for_backward(wk, sp, *saved)
             ctx.K, ctx.prop_time, ctx.plan, ctx.valid_w = K, int(prop_time), plan, int(valid_w)
             ctx.x_dtype, ctx.g_dtype = x.dtype, guided.dtype
-        return out.unsqueeze(1)
+        return outs[0].unsqueeze(1) if CX == 1 else torch.stack(outs, 1)
 
     @staticmethod
     def backward(ctx, grad_out):
-        wk, d0, sp, hist = ctx.saved_tensors
-        B, H, W = d0.shape
+        wk, sp = ctx.saved_tensors[:2]
+        planes = ctx.saved_tensors[2:]
+        CX = len(planes) // 2
+        B, H, W = planes[0].shape
         K, T = ctx.K, ctx.prop_time
         NT = K * K - 1
         L = _lib.lib()
-        g_T, ghist = _reverse_sweep(wk, K, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
-        gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
-        if _tail_vector_ok(W, wk, d0, sp, hist, gg):
-            gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
-            with _device_guard(wk.device):
-                ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
-                                              _dt(wk), B, H, W, K, T, _stream(wk.device))
-            _lib.check(ok, "cspn_pac_backward_tail")
-        else:
-            gw, gx0 = _grad_weights(wk, K, T, d0, hist, sp, g_T, ghist)
-            with _device_guard(wk.device):
-                ok = L.cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, K, _stream(wk.device))
-            _lib.check(ok, "cspn_pac_grad_guided")
-        if not ctx.needs_input_grad[1]:
-            gg = None
-        gx = gx0.to(ctx.x_dtype).unsqueeze(1) if ctx.needs_input_grad[0] else None
+        go = grad_out.contiguous().float()
+        gg_sum, gxs = None, []
+        for c in range(CX):
+            d0, hist = planes[2 * c], planes[2 * c + 1]
+            g_T, ghist = _reverse_sweep(wk, K, T, sp, go[:, c].contiguous(), ctx.plan, ctx.valid_w)
+            gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
+            if _tail_vector_ok(W, wk, d0, sp, hist, gg):
+                gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
+                with _device_guard(wk.device):
+                    ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
+                                                  _dt(wk), B, H, W, K, T, _stream(wk.device))
+                _lib.check(ok, "cspn_pac_backward_tail")
+            else:
+                gw, gx0 = _grad_weights(wk, K, T, d0, hist, sp, g_T, ghist)
+                with _device_guard(wk.device):
+                    ok = L.cspn_pac_grad_guided(_p(wk), _dt(wk), _p(gw), _p(gg), _dt(gg), B, H, W, K, _stream(wk.device))
+                _lib.check(ok, "cspn_pac_grad_guided")
+            gxs.append(gx0)
+            if CX > 1:
+                gg_sum = gg.float() if gg_sum is None else gg_sum.add_(gg)
+            else:
+                gg_sum = gg
+        gg = gg_sum.to(ctx.g_dtype) if ctx.needs_input_grad[1] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (gxs[0].unsqueeze(1) if CX == 1 else torch.stack(gxs, 1)).to(ctx.x_dtype)
         return gx, gg, None, None, None, None, None
 
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 3
+#define CSPN_ABI_VERSION 4
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -213,6 +213,11 @@ typedef struct cspn_conv_geometry {
 
 /* Output extent for an input extent under `geom` (pac.py:41-42); writes Ho, Wo; 0 if the result is empty/invalid. */
 int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int* Wo);
+
+/* A/B + test switch (process-wide): on != 0 makes every cspn_pac_* entry skip its LDS-tiled kernels and run the generic
+ * one-quad-per-thread kernels; the previous setting is stored to *previous_or_null.  The initial value is read once from
+ * CSPN_PAC_SCALAR=1 in the environment (the hot path never calls getenv).  Results are identical either way. */
+int cspn_pac_force_generic(int on, int* previous_or_null);
 
 /* Conv2dFn.forward (pac.py:75-94) == the native_impl branch (pac.py:130-140). */
 int cspn_pac_conv2d(const void* input, const void* kernel, void* out, int dtype, int B, int C, int kernel_ch,

@@ -136,3 +136,21 @@ def test_fp16_backward_runs_and_tracks_fp32(c_oracle):
         o = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=state)(xt, gdt)
         o.backward(dev(cot.astype(np.float32 if state == "reference" else np.float16)))
         assert close(xt.grad.float().cpu().numpy(), wx, 1e-2) and close(gdt.grad.float().cpu().numpy(), wgd, 3e-2)
+
+
+@pytest.mark.parametrize("name", golden_names("g11_"))
+def test_pac_multichannel_golden(name):
+    """CSPN_ours with x [B,C>1,H,W] (VERDICT r01 missing #3 / ADVICE): forward vs the reference module, gradients vs the
+    reference's autograd (goldens G11)."""
+    z = load_golden(name)
+    x, gd = dev(z["x"], True), dev(z["guided"], True)
+    out = pkg.CSPN_ours.AffinityPropagate(int(z["T"]))(x, gd, sparse_depth=dev(z.get("sparse")))
+    assert out.shape == x.shape
+    o = out.detach().cpu().numpy()
+    assert float((np.abs(o - z["out"]) / np.maximum(np.abs(z["out"]), 1e-6)).max()) <= 1e-5, name
+    out.backward(dev(z["cot"]))
+    assert close(x.grad.cpu().numpy(), z["grad_x"], 5e-5), name
+    assert close(gd.grad.cpu().numpy(), z["grad_guided"], 5e-4), name
+    with torch.no_grad():
+        o2 = pkg.CSPN_ours.AffinityPropagate(int(z["T"]))(x.detach(), gd.detach(), sparse_depth=dev(z.get("sparse")))
+    assert torch.equal(o2, out.detach())

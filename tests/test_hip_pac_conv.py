@@ -23,6 +23,24 @@ def dev(x, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
+class force_generic(object):
+    """with force_generic(1): every cspn_pac_* call runs the generic kernels (include/cspn_hip.h cspn_pac_force_generic)."""
+
+    def __init__(self, on):
+        self.on = int(on)
+
+    def __enter__(self):
+        import ctypes
+        from cspn_monodepth_amd import _lib
+        self.prev = ctypes.c_int(0)
+        assert _lib.lib().cspn_pac_force_generic(self.on, ctypes.byref(self.prev))
+
+    def __exit__(self, *exc):
+        from cspn_monodepth_amd import _lib
+        assert _lib.lib().cspn_pac_force_generic(self.prev.value, None)
+        return False
+
+
 def geom_of(z):
     kh, kw, sh, sw, ph, pw, dh, dw = (int(v) for v in z["geom"][:8])
     return (kh, kw), (sh, sw), (ph, pw), (dh, dw)
@@ -116,8 +134,8 @@ def test_fuzz_geometry_vs_oracle(seed):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_fuzz_tiled_geometry_both_kernels(seed, monkeypatch):
-    """Stride 1 / dilation 1 / square K in {3,5,7} takes the LDS-tiled kernels; CSPN_PAC_SCALAR=1 forces the generic
+def test_fuzz_tiled_geometry_both_kernels(seed):
+    """Stride 1 / dilation 1 / square K in {3,5,7} takes the LDS-tiled kernels; cspn_pac_force_generic(1) forces the generic
     ones.  Both must match the oracle on frames that span several 64 x 16 tiles, ragged edges included."""
     rng = np.random.default_rng(2000 + seed)
     K = (3, 5, 7)[seed % 3]
@@ -139,18 +157,18 @@ def test_fuzz_tiled_geometry_both_kernels(seed, monkeypatch):
     wgi, wgk = porc.pac_conv2d_backward(x, kern, cot, K, 1, p, 1)
     tol = 2e-3 if dt == torch.float16 else TOL
     tag = (B, C, CK, H, W, K, p, str(dt))
-    for scalar in ("0", "1"):
-        monkeypatch.setenv("CSPN_PAC_SCALAR", scalar)
-        out, gi, gk = run_all(x, kern, cot, K, 1, p, 1, dt)
+    for scalar in (0, 1):
+        with force_generic(scalar):
+            out, gi, gk = run_all(x, kern, cot, K, 1, p, 1, dt)
         assert nmax(out, want) <= tol, (tag, scalar)
         assert nmax(gi, wgi) <= tol, (tag, scalar)
         assert nmax(gk, wgk) <= tol, (tag, scalar)
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed, monkeypatch):
+def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed):
     """Unit stride with dilation / non-square / even windows takes the any-geometry LDS-tiled forward; compare it and the
-    scalar kernel (CSPN_PAC_SCALAR=1) with the oracle on multi-tile frames."""
+    scalar kernel (cspn_pac_force_generic) with the oracle on multi-tile frames."""
     rng = np.random.default_rng(3000 + seed)
     k = (int(rng.integers(1, 6)), int(rng.integers(1, 6)))
     d = (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
@@ -165,9 +183,8 @@ def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed, monkeypatch):
     x = rng.standard_normal((B, C, H, W)).astype(np.float32)
     kern = rng.standard_normal((B, CK, k[0], k[1], Ho, Wo)).astype(np.float32)
     want = porc.pac_conv2d_forward(x, kern, k, 1, p, d, dtype=np.float64)
-    for scalar in ("0", "1"):
-        monkeypatch.setenv("CSPN_PAC_SCALAR", scalar)
-        with torch.no_grad():
+    for scalar in (0, 1):
+        with force_generic(scalar), torch.no_grad():
             out = pac.conv2d(dev(x), dev(kern), k, 1, p, d).cpu().numpy()
         assert nmax(out, want) <= TOL, (B, C, CK, H, W, k, p, d, scalar)
 
@@ -256,3 +273,36 @@ def test_only_needed_gradients_are_computed():
     x2 = x.clone().requires_grad_(True)
     pac.conv2d(x2, k.detach(), 3, 1, 1, 1).sum().backward()
     assert x2.grad is not None
+
+
+@pytest.mark.parametrize("name", golden_names("g12_nd2col_grad_"))
+def test_nd2col_is_differentiable(name):
+    """the reference's nd2col is differentiable (pac.py:51-68 via F.unfold); the HIP nd2col's backward
+    is the fold.  Golden = reference autograd of sum(cols * cot)."""
+    z = load_golden(name)
+    g = [int(v) for v in z["geom"]]
+    x = dev(z["x"]).requires_grad_(True)
+    cols = pac.nd2col(x, (g[0], g[1]), (g[2], g[3]), (g[4], g[5]), (g[8], g[9]), (g[6], g[7]), bool(g[10]))
+    assert cols.requires_grad
+    (cols * dev(z["cot"])).sum().backward()
+    want = z["grad_x"]
+    assert x.grad.shape == want.shape
+    assert float(np.abs(x.grad.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))
+    # no-grad call: plain tensor, same values
+    with torch.no_grad():
+        c2 = pac.nd2col(x, (g[0], g[1]), (g[2], g[3]), (g[4], g[5]), (g[8], g[9]), (g[6], g[7]), bool(g[10]))
+    assert not c2.requires_grad and torch.equal(c2, cols.detach())
+
+
+def test_native_impl_formulation_backpropagates_through_nd2col():
+    """pac.py:130-140 written out with this package's nd2col: gradients equal Conv2dFn's (G9 golden)."""
+    z = load_golden("g9_k3_same_shared")
+    k, s, p, d = geom_of(z)
+    x, kern = dev(z["x"]).requires_grad_(True), dev(z["kernel"]).requires_grad_(True)
+    cols = pac.nd2col(x, k, stride=s, padding=p, dilation=d)
+    out = (cols * kern).sum(dim=(2, 3))
+    out.backward(dev(z["cot"]))
+    assert float(np.abs(out.detach().cpu().numpy() - z["out"]).max()) < 1e-5
+    for got, key in ((x.grad, "grad_input_f64"), (kern.grad, "grad_kernel_f64")):
+        want = z[key]
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))

@@ -117,3 +117,16 @@ def test_plumbing_port_matches_oracle():
     with torch.no_grad():
         out = plumb.pac_plumbing(torch.from_numpy(x), torch.from_numpy(gd), None, 5).numpy()
     assert rel_err(out, orc.pac_forward(x, gd, None, 5)) <= FWD_TOL
+
+
+@pytest.mark.parametrize("name", golden_names("g11_"))
+def test_pac_multichannel_golden(name):
+    """x [B,C>1,H,W] through CSPN_ours (CSPN_ours.py:24-29; pac.py:89-92 broadcast): forward from the module, gradients
+    from the reference's autograd through pac.conv2d(native_impl=True)."""
+    z = load_golden(name)
+    T = int(z["T"])
+    assert z["x"].shape[1] > 1 and z["out"].shape == z["x"].shape
+    out = orc.pac_forward_multichannel(z["x"], z["guided"], _sp(z), T)
+    assert rel_err(out, z["out"]) <= FWD_TOL, name
+    gx, gg = orc.pac_backward_multichannel(z["x"], z["guided"], _sp(z), z["cot"], T, np.float64)
+    assert np.abs(gx - z["grad_x"]).max() <= 1e-10 and np.abs(gg - z["grad_guided"]).max() <= 1e-10

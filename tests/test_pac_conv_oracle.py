@@ -91,3 +91,12 @@ def test_host_interface_mirrors_reference():
         pac.conv2d(torch.zeros(1, 3, 4, 4), torch.zeros(1, 1, 3, 3, 4, 4), 3, 1, 1, 1)
     with pytest.raises(RuntimeError, match="ROCm device"):
         pac.nd2col(torch.zeros(1, 1, 4, 4), 3)
+
+
+@pytest.mark.parametrize("name", golden_names("g12_nd2col_grad_"))
+def test_oracle_nd2col_backward_matches_reference_autograd(name):
+    z = load_golden(name)
+    g = [int(v) for v in z["geom"]]
+    gx = porc.nd2col_backward(z["cot"].astype(np.float64), z["x"].shape[-2:], (g[0], g[1]), (g[2], g[3]), (g[4], g[5]),
+                              (g[8], g[9]), (g[6], g[7]), bool(g[10]))
+    assert gx.shape == z["grad_x"].shape and np.abs(gx - z["grad_x"]).max() < 1e-12
