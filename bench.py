@@ -43,6 +43,9 @@ WORKLOADS = {
                     name="NYU-v2 304x228 batch=24, 5x5 softmax affinity, 12 iters, fp32"),
     "pac5": dict(B=24, H=228, W=304, K=5, T=12, dtype="f16", C=24,
                  name="NYU-v2 304x228 batch=24, 5x5 softmax affinity, 12 iters, fp16 (BASELINE config 3)"),
+    "train": dict(B=3, H=228, W=304, K=3, T=24, dtype="f32", C=12,
+                  name="NYU-v2 training step: ResNet-50 UNet + affinity head (stock PyTorch-ROCm) + HIP CSPN forward/backward, "
+                       "batch 3 per GPU (BASELINE config 5: global batch 24 on 8 GPUs, DDP + SyncBatchNorm)"),
 }
 
 
@@ -72,11 +75,48 @@ def make_inputs(wl, B, device, seed, sparse):
     return g, d, s, target
 
 
+def load_pmc_traffic(tag):
+    """HBM traffic per launch from the committed rocprofv3 --pmc summary of this workload (profiles/*_pmc_traffic_<tag>
+    .json, newest round first).  `stale` = the kernel sources changed since the file was measured."""
+    import glob
+    out = {"source": None, "stale": None, "step_bytes_per_launch": None, "fused_bytes_per_forward": None,
+           "fused_per_launch": None, "sq": None}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % tag)), reverse=True)
+    if not files:
+        return out
+    try:
+        j = json.load(open(files[0]))
+    except Exception:
+        return out
+    out["source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, gfx950-corrected%s)" % (
+        os.path.basename(files[0]), "; measured at commit %s" % j["commit"] if j.get("commit") else "")
+    try:
+        out["stale"] = (j.get("source_digest") != pkg._lib._source_digest([])) if j.get("source_digest") else None
+    except Exception:
+        out["stale"] = None
+    pk = j.get("per_kernel", {})
+    fused = [(k, v) for k, v in pk.get("fused", {}).items() if k.startswith("cspn_prop") and "hbm_bytes_corrected" in v]
+    if fused:
+        n_fwd = min(v["_dispatches_FETCH_SIZE"] for _, v in fused)       # every instance runs >= once per forward
+        out["fused_per_launch"] = {k: v["hbm_bytes_corrected"] for k, v in fused}
+        out["fused_bytes_per_forward"] = sum(v["hbm_bytes_corrected"] * v["_dispatches_FETCH_SIZE"] for _, v in fused) / n_fwd
+    step = [(k, v) for k, v in pk.get("step", {}).items() if k.startswith("cspn_prop") and "hbm_bytes_corrected" in v]
+    if step:                                                             # the plain streaming instance dominates
+        out["step_bytes_per_launch"] = max(step, key=lambda kv: kv[1]["_dispatches_FETCH_SIZE"])[1]["hbm_bytes_corrected"]
+    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_%s.json" % tag)), reverse=True)
+    if sq:
+        try:
+            out["sq"] = dict(json.load(open(sq[0])), source="profiles/" + os.path.basename(sq[0]))
+        except Exception:
+            pass
+    return out
+
+
 def cpu_baseline(wl, budget_s=16.0):
     """The reference's CPU op mix (oracle/ref_plumbing_torch.py, a port validated bit-identical to the imported
     reference) on this box's host cores, on a bounded sample of the same workload: single frames and a
-    4-frame batch of the workload's shape, at up to four thread counts (1/8/16/32, capped by the core count;
-    256 threads take >60 s per frame) (oneDNN's 5-D conv path scales badly with both
+    4-frame batch of the workload's shape, at up to four thread counts (1/8/16/32, capped by the core count) plus one
+    all-threads leg in a child process with a timeout (oneDNN's 5-D conv path scales badly with both
     batch and threads); the best rate is reported."""
     from oracle import ref_plumbing_torch as plumb
     from oracle import c_oracle
@@ -112,6 +152,32 @@ def cpu_baseline(wl, budget_s=16.0):
                 tried.append({"threads": threads, "batch": b, "maps_per_s": rate, "reps": len(times)})
                 if best is None or rate > best[0]:
                     best = (rate, threads, b, len(times))
+    # all host threads (SURVEY.md 8d asks for os.cpu_count() next to 1): oneDNN's 5-D conv path can take minutes per
+    # frame at 256 threads, so this leg runs in a child process that is killed after `all_core_timeout_s`
+    all_cores = None
+    if cores > 32:
+        import subprocess
+        code = ("import sys, time, json, torch; sys.path.insert(0, %r); from oracle import ref_plumbing_torch as p; "
+                "torch.set_num_threads(%d); torch.manual_seed(0); "
+                "g, d = torch.randn(1, %d, %d, %d), torch.rand(1, 1, %d, %d) * 10; "
+                "f = (lambda: p.cspn3_plumbing(g, d, None, %d)) if %d == 3 else (lambda: p.pac_plumbing(d, g, None, %d)); "
+                "f(); ts = []\n"
+                "for _ in range(3):\n    t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)\n"
+                "print(json.dumps({'maps_per_s': 1.0 / sorted(ts)[1], 'reps': 3}))" % (
+                    ROOT, cores, 8 if wl["K"] == 3 else wl["C"], H, W, H, W, T, wl["K"], T))
+        all_core_timeout_s = 45
+        try:
+            with torch.no_grad():
+                cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=all_core_timeout_s)
+            all_cores = dict(json.loads(cp.stdout.strip().splitlines()[-1]), threads=cores, batch=1)
+            tried.append({"threads": cores, "batch": 1, "maps_per_s": all_cores["maps_per_s"], "reps": 3})
+            if all_cores["maps_per_s"] > best[0]:
+                best = (all_cores["maps_per_s"], cores, 1, 3)
+        except subprocess.TimeoutExpired:
+            all_cores = {"threads": cores, "batch": 1, "timed_out_after_s": all_core_timeout_s,
+                         "maps_per_s_upper_bound": 4.0 / all_core_timeout_s}
+        except Exception as e:                                         # noqa: BLE001
+            all_cores = {"threads": cores, "error": repr(e)[:200]}
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -123,6 +189,7 @@ def cpu_baseline(wl, budget_s=16.0):
     one = [t for t in tried if t["threads"] == 1]
     out = {"value": best[0], "unit": "depth-maps/s", "cores": best[1], "kind": "port", "host_cores": cores,
            "cpu_model": model, "single_thread_value": max(t["maps_per_s"] for t in one) if one else None,
+           "all_threads_leg": all_cores,
            "sample": "%d forward(s) of %d frame(s) %dx%d, T=%d (median, after warm-up) with %d of %d host threads; "
                      "PyTorch %s CPU op-mix port of the reference (pad/cat/conv3d-ones/div); legs tried: %s" % (
                          best[3], best[2], W, H, T, best[1], cores, torch.__version__, json.dumps(tried))}
@@ -135,6 +202,106 @@ def cpu_baseline(wl, budget_s=16.0):
     except Exception as e:  # pragma: no cover
         out["c_oracle_error"] = repr(e)
     return out
+
+
+def run_train(args, wl, world, rank, local_rank, device):
+    """BASELINE config 5: one optimiser step of the re-hosted unet_cspn_nyu topology (cspn_monodepth_amd/network/
+    unet_cspn_nyu.py: stock PyTorch-ROCm convolutions + the HIP un-pooling + the HIP CSPN module in forward AND
+    backward), MaskedL1Loss (libs/criterion/criteria.py:27-39), SGD (main.py:72-74), synthetic RGB-D batch of
+    `B` frames per GPU; N > 1: DistributedDataParallel over RCCL + nn.SyncBatchNorm (weak scaling: the global batch
+    grows with N, config 5 = 3 x 8).  Reports depth-maps/s through the whole step and the CSPN module's share of it
+    (HIP events recorded by module hooks on the launch stream, inside the timed region)."""
+    from cspn_monodepth_amd.network import unet_cspn_nyu
+    import torch.nn as nn
+    B, H, W = wl["B"], wl["H"], wl["W"]
+    torch.manual_seed(0)
+    model = unet_cspn_nyu.resnet50(reference_state_dict=False, cspn_plan=parse_plan(args.plan)).to(device)
+    if world > 1:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        ddp = nn.parallel.DistributedDataParallel(model, device_ids=[device.index] if args.backend == "nccl" else None,
+                                                  gradient_as_bucket_view=True)
+    else:
+        ddp = model
+    opt = torch.optim.SGD(model.parameters(), lr=0.001, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator(device=device).manual_seed(4321 + rank)
+    depth = (torch.rand(B, 1, H, W, device=device, generator=gen) * 9.5 + 0.5)
+    rgb = torch.rand(B, 3, H, W, device=device, generator=gen)
+    sparse = depth * (torch.rand(B, 1, H, W, device=device, generator=gen) < 500.0 / (H * W))
+    x = torch.cat([rgb, sparse], 1)
+    target = torch.where(torch.rand(B, 1, H, W, device=device, generator=gen) < 0.05, torch.zeros_like(depth), depth)
+
+    cspn = model.post_process_layer
+    ev = {"f0": [], "f1": [], "b0": [], "b1": []}
+    timing = {"on": False}
+
+    def rec(key):
+        def hook(*_):
+            if timing["on"]:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev[key].append(e)
+        return hook
+    cspn.register_forward_pre_hook(rec("f0"))
+    cspn.register_forward_hook(rec("f1"))
+    cspn.register_full_backward_pre_hook(rec("b0"))
+    cspn.register_full_backward_hook(rec("b1"))
+
+    losses = []
+
+    def step():
+        pred = ddp(x)
+        valid = target > 0
+        loss = ((target - pred).abs() * valid).sum() / valid.sum()          # MaskedL1Loss
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timing["on"] = True
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    timing["on"] = False
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    fwd_us = sorted(a.elapsed_time(b) * 1e3 for a, b in zip(ev["f0"], ev["f1"]))
+    bwd_us = sorted(a.elapsed_time(b) * 1e3 for a, b in zip(ev["b0"], ev["b1"]))
+    med = lambda v: v[len(v) // 2] if v else None                           # noqa: E731
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        lv = [float(v) for v in losses]
+        res = {"metric": "depth-maps/sec through one training step (%s)" % wl["name"],
+               "value": B * world * args.steps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic RGB-D batch (random-init weights; no dataset / checkpoint on the box)",
+               "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
+                          "prop_time": wl["T"], "optimizer": "SGD(momentum 0.9, wd 1e-4)", "loss": "MaskedL1",
+                          "parameters": int(sum(p.numel() for p in model.parameters())),
+                          "parallelism": "DDP x%d over RCCL + SyncBatchNorm" % world if world > 1 else "single GPU"},
+               "roofline": None,
+               "cspn_module": {"forward_us_p50": med(fwd_us), "backward_us_p50": med(bwd_us),
+                               "share_of_step": ((med(fwd_us) or 0) + (med(bwd_us) or 0)) / (ms * 1e3),
+                               "note": "HIP events from module hooks around CSPN_new.AffinityPropagate's forward (derive launch "
+                                       "+ history) and backward (reverse sweep + fused tail); the rest of the step is stock "
+                                       "MIOpen/rocBLAS convolutions, batch-norm, the un-pooling kernel, SGD"},
+               "loss_first_last": [lv[0], lv[-1]]}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -183,15 +350,21 @@ def main():
     if args.batch > 0:
         wl["B"] = args.batch
         wl["name"] += " [batch overridden to %d]" % args.batch
+    if args.workload == "train":
+        return run_train(args, wl, world, rank, local_rank, device)
     strong = args.workload == "kitti"
-    if strong:                                        # config 4: the batch of 8 is sharded across the ranks
-        lo, hi = pkg.evaluation.shard_bounds(wl["B"], rank, world)
-        B_local = hi - lo
-    else:
-        B_local = wl["B"]
     plan = parse_plan(args.plan)
     K, T = wl["K"], wl["T"]
-    g, d, s, target = make_inputs(wl, max(B_local, 1), device, seed=1234 + rank, sparse=args.sparse)
+    if strong:                                        # config 4: ONE batch of 8, sharded across the ranks (contiguous chunks)
+        lo, hi = pkg.evaluation.shard_bounds(wl["B"], rank, world)
+        B_local = hi - lo
+        full = make_inputs(wl, wl["B"], device, seed=1234, sparse=args.sparse)      # every rank regenerates the same batch
+        lo_ = min(lo, wl["B"] - 1)                     # a rank beyond the batch keeps one frame so its launches are valid; it counts 0
+        g, d, s, target = (None if t is None else t[lo_:max(hi, lo_ + 1)].contiguous() for t in full)
+        del full
+    else:
+        B_local = wl["B"]
+        g, d, s, target = make_inputs(wl, B_local, device, seed=1234 + rank, sparse=args.sparse)
     if K == 3:
         module = pkg.CSPN_new.AffinityPropagate(T, 3, plan=plan)
         run = lambda: module(g, d, s)                                  # noqa: E731
@@ -303,33 +476,34 @@ def main():
     alg_bytes_per_launch = bytes_px_step * B_local * wl["H"] * wl["W"] * (T / max(1, -(-T // S)))
     avg_launch_s = (prop_ms / 1e3) / max(n_launch, 1)
     achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # measured HBM traffic (rocprofv3 --pmc passes, tools/pmc_session.sh -> tools/pmc_traffic.py): NOT collected by this
+    # run — counters need their own rocprofv3 passes — so the figures are quoted from the committed summary together with
+    # the source digest of the kernels they were measured on (`traffic_stale` = the kernels changed since).
+    pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""))
 
-    # ---- the north-star "one kernel per propagation step" schedule (S = 1), measured in the same process
+    # ---- the north-star schedule: ONE launch per propagation step (S = 1), measured in the same process.  This is the
+    # HBM-bound kernel the contract's `roofline` block describes: its algorithmic bytes ARE its HBM traffic.
     per_step = None
-    if rank == 0 and S != 1 and K == 3 and not args.no_per_step_leg:
-        # best S = 1 plan for this shape: time the one-step candidates once (host-side autotuner, S restricted to 1)
+    if rank == 0 and not args.no_per_step_leg:
         with torch.no_grad():
-            w1, _, _ = F.cspn3_prepare(g)
-            d1 = d[:, 0].contiguous()
+            if K == 3:
+                w1, _, _ = F.cspn3_prepare(g)
+                d1 = d[:, 0].contiguous()
+            else:
+                w1, _ = F.pac_prepare(g)
+                d1 = d[:, 0].contiguous()
             s1 = None if s is None else s[:, 0].contiguous()
             bl1 = F.BLEND_SPARSE if s is not None else F.BLEND_NONE
             best_us, p1 = float("inf"), None
-            for cand in F.candidate_plans(3, wl["H"], wl["W"], 1):
+            for cand in F.candidate_plans(K, wl["H"], wl["W"], 1):       # host-side autotuner restricted to S = 1
                 if cand["steps_per_launch"] != 1:
                     continue
                 try:
-                    F.propagate(w1, d1, s1, 3, T, bl1, plan=cand)
+                    F.propagate(w1, d1, s1, K, T, bl1, plan=cand)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(3):
-                        F.propagate(w1, d1, s1, 3, T, bl1, plan=cand)
+                        F.propagate(w1, d1, s1, K, T, bl1, plan=cand)
                     e1.record()
                     e1.synchronize()
                 except RuntimeError:
@@ -340,23 +514,63 @@ def main():
         ev1 = F.EventLog(n1)
         with torch.no_grad():
             for _ in range(5):
-                F.propagate(w1, d1, s1, 3, T, bl1, plan=p1)
+                F.propagate(w1, d1, s1, K, T, bl1, plan=p1)
             F.set_event_log(ev1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n1):              # one forward of the per-step schedule = prepare + T one-step launches
-                w1, _, _ = F.cspn3_prepare(g)
-                F.propagate(w1, d1, s1, 3, T, bl1, plan=p1)
+                if K == 3:
+                    w1, _, _ = F.cspn3_prepare(g)
+                else:
+                    w1, _ = F.pac_prepare(g)
+                F.propagate(w1, d1, s1, K, T, bl1, plan=p1)
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t0
             F.set_event_log(None)
         del w1
         ms1 = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ev1)
         nl1 = sum(n for _, _, n, _ in ev1)
-        a1 = bytes_px_step * B_local * wl["H"] * wl["W"] / (ms1 / 1e3 / nl1) / 1e9
-        per_step = {"bound": "hbm", "kernel": "cspn_prop_fused (S=1)", "achieved": a1, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "avg_launch_us": ms1 * 1e3 / nl1,
-                    "launches_timed": nl1, "maps_per_s_forward_only": B_local * n1 / dt1, "plan": p1}
+        alg1 = bytes_px_step * B_local * wl["H"] * wl["W"]
+        a1 = alg1 / (ms1 / 1e3 / nl1) / 1e9
+        per_step = {"bound": "hbm", "kernel": "cspn_prop_fused<%d,...> S=1 (one launch per propagation step)" % K,
+                    "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
+                    "traffic": pmc["step_bytes_per_launch"], "traffic_source": pmc["source"],
+                    "traffic_stale": pmc["stale"],
+                    "algorithmic_bytes_per_launch": alg1, "bytes_per_px_step": bytes_px_step,
+                    "avg_launch_us": ms1 * 1e3 / nl1, "launches_timed": nl1, "steps_per_launch": 1,
+                    "maps_per_s_forward_only": B_local * n1 / dt1, "plan": p1,
+                    "note": "HIP events on the launch stream around each T-launch loop (launch gaps included) / T; "
+                            "SURVEY.md 8(d): (K^2+1)*sizeof(T) bytes per pixel per step"}
+
+    # ---- the default (temporally blocked) schedule, the one `value` is measured on: S steps per launch keep the depth
+    # tile in LDS, so a launch moves FEWER HBM bytes than S x the per-step algorithmic bytes — HBM is then not its bound
+    # and algorithmic bytes / time is an EFFECTIVE rate, not a roofline fraction.
+    launches_fwd = -(-T // max(S, 1))
+    esz_g = esz
+    # what a forward cannot avoid moving: K^2-1 guidance planes + coarse depth in, refined depth out (+ the sparse
+    # plane, + the target plane the fused metrics read)
+    compulsory = B_local * wl["H"] * wl["W"] * ((K * K - 1) * esz_g + 2 * esz + (esz if args.sparse else 0) +
+                                                (0 if args.no_metrics else esz))
+    fused = {"kernel": "cspn_prop_fused<%d,...> S=%d (%d launches per forward)" % (K, S, launches_fwd),
+             "bound": "valu+lds (temporal blocking: the step loop runs out of LDS/VGPRs, HBM traffic is below the "
+                      "algorithmic bytes)" if S > 1 else "hbm",
+             "steps_per_launch": S, "launches_per_forward": launches_fwd,
+             "avg_launch_us": avg_launch_s * 1e6, "launches_timed": n_launch,
+             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+             "effective_algorithmic_GBs": achieved,
+             "effective_over_hbm_peak": achieved / HBM_PEAK_GBS,
+             "compulsory_bytes_per_forward": compulsory,
+             "hbm_traffic_bytes_per_forward": pmc["fused_bytes_per_forward"],
+             "hbm_traffic_per_launch": pmc["fused_per_launch"],
+             "traffic_source": pmc["source"], "traffic_stale": pmc["stale"],
+             "propagation_us_per_forward_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)]}
+    if pmc["fused_bytes_per_forward"] and n_launch:
+        fwd_s = avg_launch_s * launches_fwd
+        fused["hbm_GBs_on_measured_traffic"] = pmc["fused_bytes_per_forward"] / fwd_s / 1e9
+        fused["frac_hbm_on_measured_traffic"] = fused["hbm_GBs_on_measured_traffic"] / HBM_PEAK_GBS
+        fused["traffic_over_compulsory"] = pmc["fused_bytes_per_forward"] / compulsory
+    if pmc.get("sq"):
+        fused["sq_counters"] = pmc["sq"]
 
     # ---- cache-cold leg: rotate over input sets whose footprint exceeds the 256 MiB Infinity
     # Cache, so that no forward finds its guidance / depth / target resident from the previous one
@@ -453,25 +667,16 @@ def main():
                        "prop_time": T, "guidance_channels": wl["C"], "sparse": bool(args.sparse),
                        "step": "prepare + %d propagation steps%s" % (T, "" if args.no_metrics else " + depth metrics (fused into the last launch)"),
                        "plan": eff_plan, "hip_graph": bool(use_graph), "parallelism": "batch-shard x%d, metrics all-gather" % world},
-            "roofline": {"bound": "hbm", "kernel": "cspn_prop_fused", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": n_launch,
-                         "steps_per_launch": S, "bytes_per_px_step": bytes_px_step,
-                         "propagation_us_per_step_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)],
-                         "note": "HIP events around each propagation loop inside the timed region (launch gaps "
-                                 "included) / launches; S>1 = temporal blocking, so algorithmic bytes per launch "
-                                 "exceed what the launch reads from HBM"},
+            "roofline": per_step if per_step is not None else (
+                dict(fused, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None)
+                if S == 1 else None),
+            "default_schedule": fused,
             "metrics_check": {k: v for k, v in pkg.evaluation.finalize_metrics(total.cpu()).items()
                               if k in ("rmse", "absrel", "delta1", "count")},
         }
-        if copy_gbs:
+        if copy_gbs and res["roofline"] is not None:
             res["roofline"]["device_copy_GBs"] = copy_gbs
-        if per_step is not None:
-            if copy_gbs:
-                per_step["device_copy_GBs"] = copy_gbs
-                per_step["frac_of_device_copy"] = per_step["achieved"] / copy_gbs
-            res["roofline_per_step_schedule"] = per_step
+            res["roofline"]["frac_of_device_copy"] = res["roofline"]["achieved"] / copy_gbs
         if cold is not None:
             res["cache_cold"] = cold
         if train is not None:

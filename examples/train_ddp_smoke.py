@@ -7,9 +7,11 @@ DistributedDataParallel over RCCL when launched with torchrun:
     python examples/train_ddp_smoke.py                                   # one GPU
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ddp_smoke.py
 
-The 256 M-parameter ResNet-50 UNet itself is out of scope (stock ops); this small network has
-the same tensor contract at the CSPN boundary (guidance [B,12,H,W], coarse [B,1,H,W], sparse = input[:,3:4]).
-Synthetic data (no dataset on the box).
+`--model resnet50` trains the re-hosted reference topology (cspn_monodepth_amd/network/unet_cspn_nyu.py: ResNet-50
+encoder, guided up-projection decoder on the HIP un-pooling kernel, both heads — 218 M parameters in use); the default
+`--model tiny` is a five-conv network with the same tensor contract at the CSPN boundary (guidance [B,12,H,W], coarse
+[B,1,H,W], sparse = input[:,3:4]) for quick smoke runs.  `bench.py --workload train` is the measured version of the
+resnet50 step.  Synthetic data (no dataset on the box).
 """
 import argparse
 import os
@@ -65,6 +67,7 @@ def main(argv=None):
     ap.add_argument("--H", type=int, default=228)
     ap.add_argument("--W", type=int, default=304)
     ap.add_argument("--lr", type=float, default=0.02)
+    ap.add_argument("--model", choices=("tiny", "resnet50"), default="tiny")
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -74,7 +77,13 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     torch.manual_seed(0)
-    model = TinyDepthNet().to(device)
+    if args.model == "resnet50":
+        if (args.H, args.W) != (228, 304):
+            raise SystemExit("--model resnet50 uses the reference's 228x304 decoder pyramid (unet_cspn_nyu.py:327-332)")
+        from cspn_monodepth_amd.network import unet_cspn_nyu
+        model = unet_cspn_nyu.resnet50(reference_state_dict=False).to(device)
+    else:
+        model = TinyDepthNet().to(device)
     if world > 1:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)               # replaces In-Place ABN sync
         model = nn.parallel.DistributedDataParallel(model, device_ids=[local])

@@ -117,9 +117,51 @@ def g12():
         assert e < 1e-12, (name, e)
 
 
+def g13():
+    """Host model of config 5 (network/unet_cspn_nyu.py): (a) the reference's state_dict keys + shapes (checkpoint
+    compatibility), (b) one decoder block of each kind on small tensors with its weights stored, (c) the full seeded,
+    untrained resnet50 on one 228x304 RGB-D frame: the tensors handed to the CSPN module and the refined depth,
+    sub-sampled (the weights are regenerated on the test side from the same seed and construction order)."""
+    from network import unet_cspn_nyu as ref_net
+    torch.manual_seed(0)
+    net = ref_net.resnet50(pretrained=False).eval()
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(HERE, "g13_unet_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    manifest["g13_params"] = int(sum(p.numel() for p in net.parameters()))
+    cap = {}
+    net.post_process_layer.register_forward_hook(lambda m, i, o: cap.update(i=i, o=o))
+    rgb = orc.hash_uniform(130, 1, (1, 3, 228, 304), 0.0, 1.0)
+    dep = orc.hash_uniform(130, 2, (1, 1, 228, 304), 0.5, 10.0)
+    sp = orc.hash_sparse(130, 3, dep, 500.0 / (228 * 304))
+    x = np.concatenate([rgb, sp], 1)
+    with torch.no_grad():
+        out = net(t(x)).numpy()
+    gdn, coarse, sparse = (v.numpy() for v in cap["i"])
+    sub = 4
+    save("g13_unet_full", seed=np.int32(0), out_sub=out[:, :, ::sub, ::sub], guidance_sub=gdn[:, :, ::sub, ::sub],
+         coarse_sub=coarse[:, :, ::sub, ::sub], sub=np.int32(sub),
+         moments=np.array([out.astype(np.float64).sum(), (out.astype(np.float64) ** 2).sum(),
+                           gdn.astype(np.float64).sum(), (gdn.astype(np.float64) ** 2).sum()]))
+    assert np.array_equal(sparse, sp)
+    # (b) decoder blocks, train-mode BN (batch statistics) so the BN arithmetic is exercised
+    torch.manual_seed(1)
+    blocks = {"gudi": (ref_net.Gudi_UpProj_Block(6, 4, 7, 9), False), "cat": (ref_net.Gudi_UpProj_Block_Cat(6, 4, 7, 9), True),
+              "last": (ref_net.Simple_Gudi_UpConv_Block_Last_Layer(6, 3, 8, 10), False)}
+    for name, (blk, has_side) in blocks.items():
+        xin = orc.hash_normal(131, len(name), (2, 6, 4, 5))
+        side = orc.hash_normal(132, len(name), (2, 4, 7, 9)) if has_side else None
+        blk.train()
+        with torch.no_grad():
+            y = (blk(t(xin), t(side)) if has_side else blk(t(xin))).numpy()
+        sd = {"sd_" + k: v.numpy() for k, v in blk.state_dict().items() if "running" not in k and "num_batches" not in k}
+        save("g13_block_" + name, x=xin, side=side, out=y, **sd)
+
+
 if __name__ == "__main__":
     g11()
     g12()
+    g13()
     manifest["torch"] = torch.__version__
     manifest["numpy"] = np.__version__
     with open(os.path.join(HERE, "golden_r02_manifest.json"), "w") as f:

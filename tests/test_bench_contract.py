@@ -31,11 +31,16 @@ def test_single_process_json_line():
     assert d["unit"] == "depth-maps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 24 * 12 / (d["ms_per_step"] * 12 / 1e3)) / d["value"] < 1e-6
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["launches_timed"] == 12 * 3
-    p = d["roofline_per_step_schedule"]
-    assert p["plan"]["steps_per_launch"] == 1 and 0.5 < p["frac"] < 1.0       # the >= 50 % of HBM roofline target
+    r = d["roofline"]                       # the HBM-bound kernel: one launch per propagation step (north_star)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["steps_per_launch"] == 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["launches_timed"] % 24 == 0
+    assert 0.5 < r["frac"] < 1.0                                                 # the >= 50 % of HBM roofline target
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == 40 * 24 * 228 * 304
+    assert "traffic" in r and "traffic_source" in r
+    f = d["default_schedule"]               # the schedule `value` is measured on (temporal blocking)
+    assert f["launches_timed"] == 12 * f["launches_per_forward"] and f["steps_per_launch"] >= 1
+    assert "frac" not in f and f["compulsory_bytes_per_forward"] == 11 * 4 * 24 * 228 * 304
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["cache_cold"]["footprint_MB"] > 256

@@ -1,0 +1,50 @@
+"""The N > 1 code path on the hardware at hand: two (and three) processes share the ONE visible
+GPU with backend gloo — bench.py's oversubscription branch — so shard -> HIP forward_scored -> all-gather runs with
+world_size > 1 and real kernels.  (The rccl/xGMI path proper needs an 8-GPU node, which only the driver has.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _torchrun(nproc, port, script_args, timeout=600):
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port)] + script_args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return out.stdout
+
+
+@pytest.mark.parametrize("world,B", [(2, 8), (3, 8), (2, 1)])
+def test_sharded_forward_equals_unsharded_bit_for_bit(world, B):
+    """KITTI-shaped frames (config 4), full size for B=8 over 2 ranks; 3 ranks = uneven shards; B=1 = an empty shard."""
+    H, W = (352, 1216) if world == 2 else (88, 304)
+    out = _torchrun(world, 29611 + world + B, [os.path.join("tests", "dist_shard_worker.py"), "gloo", str(B), str(H), str(W), "24"])
+    assert "SHARD_CHECK_OK world=%d" % world in out, out[-2000:]
+
+
+def test_bench_two_ranks_on_one_gpu_kitti():
+    """bench.py --gpus 2 --backend gloo --workload kitti: the driver's N>1 launch line, oversubscribing the one GPU.  The
+    two ranks refine contiguous halves of ONE seeded batch, so the gathered metric sums equal the single-process run's."""
+    args = ["--steps", "4", "--warmup", "1", "--prewarm-s", "0.05", "--no-cpu-baseline", "--no-train-leg", "--cold-sets", "0",
+            "--no-per-step-leg", "--workload", "kitti"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=ROOT, capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    out = _torchrun(2, 29655, ["bench.py", "--gpus", "2", "--backend", "gloo"] + args)
+    d2 = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["batch_per_gpu"] == 4
+    assert d1["n_gpus"] == 1 and d1["config"]["batch_per_gpu"] == 8
+    assert d2["value"] > 0 and abs(d2["value"] - 8 * 4 / (d2["ms_per_step"] * 4 / 1e3)) / d2["value"] < 1e-6
+    m1, m2 = d1["metrics_check"], d2["metrics_check"]
+    assert m1["count"] == m2["count"] and m1["count"] > 0
+    for k in ("rmse", "absrel", "delta1"):
+        assert abs(m1[k] - m2[k]) <= 1e-9 * abs(m1[k]), (k, m1[k], m2[k])

@@ -1,0 +1,105 @@
+"""Host model of BASELINE config 5 (cspn_monodepth_amd/network/unet_cspn_nyu.py = the topology of the reference's
+network/unet_cspn_nyu.py:295-387 on stock PyTorch-ROCm ops + the HIP un-pooling + the HIP CSPN module).
+
+CPU: state_dict keys / shapes equal the reference's (fixture captured from the reference by make_golden_r02.py).
+GPU: decoder blocks and the full seeded network against goldens captured from the reference; one training step whose
+CSPN input/output pair and CSPN gradients match the C oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_err, rmse
+
+
+def test_state_dict_matches_reference_keys_and_shapes():
+    from cspn_monodepth_amd.network import unet_cspn_nyu
+    keys = json.load(open(os.path.join(GOLDEN, "g13_unet_state_dict_keys.json")))
+    m = unet_cspn_nyu.resnet50()
+    sd = m.state_dict()
+    assert set(sd) == set(keys)
+    assert all(list(sd[k].shape) == keys[k] for k in keys)
+    assert sum(p.numel() for p in m.parameters()) == 256080576            # golden_r02_manifest.json g13_params
+    assert len(m.post_process_layer.state_dict()) == 0                     # the CSPN module is checkpoint-transparent
+    slim = unet_cspn_nyu.resnet50(reference_state_dict=False)
+    assert set(slim.state_dict()) < set(keys) and not slim.unused_parameters()
+    used = set(id(p) for p in m.parameters()) - set(id(p) for p in m.unused_parameters())
+    assert len(used) == len(list(slim.parameters()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gudi", "cat", "last"])
+def test_decoder_blocks_match_reference(name):
+    from cspn_monodepth_amd.network import unet_cspn_nyu as net
+    z = load_golden("g13_block_" + name)
+    cls = {"gudi": net.Gudi_UpProj_Block, "cat": net.Gudi_UpProj_Block_Cat, "last": net.Simple_Gudi_UpConv_Block_Last_Layer}[name]
+    oh, ow = z["out"].shape[-2:]
+    blk = cls(z["x"].shape[1], z["out"].shape[1], oh, ow)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("sd_")}
+    missing, unexpected = blk.load_state_dict(sd, strict=False)
+    assert not unexpected and all("running" in k or "num_batches" in k for k in missing)
+    blk = blk.cuda().train()
+    x = torch.from_numpy(z["x"]).cuda()
+    with torch.no_grad():
+        y = blk(x, torch.from_numpy(z["side"]).cuda()) if name == "cat" else blk(x)
+    assert y.shape == z["out"].shape
+    assert float(np.abs(y.cpu().numpy() - z["out"]).max()) <= 2e-4 * max(1.0, float(np.abs(z["out"]).max()))
+
+
+@pytest.mark.gpu
+def test_full_network_matches_reference_and_cspn_pair_matches_oracle(c_oracle):
+    """The seeded, untrained resnet50 (same construction order => same weights as the reference's, checked when the
+    golden was made) on the golden's RGB-D frame: head outputs and refined depth vs the reference's CPU run; the CSPN
+    module's (guidance, coarse, sparse) -> out pair against the C oracle at the north-star tolerance."""
+    from cspn_monodepth_amd.network import unet_cspn_nyu as net
+    from oracle import cspn_oracle as orc
+    z = load_golden("g13_unet_full")
+    torch.manual_seed(int(z["seed"]))
+    m = net.resnet50().eval().cuda()
+    m.return_cspn_io = True
+    rgb = orc.hash_uniform(130, 1, (1, 3, 228, 304), 0.0, 1.0)
+    dep = orc.hash_uniform(130, 2, (1, 1, 228, 304), 0.5, 10.0)
+    sp = orc.hash_sparse(130, 3, dep, 500.0 / (228 * 304))
+    with torch.no_grad():
+        out, (g, c, s) = m(torch.from_numpy(np.concatenate([rgb, sp], 1)).cuda())
+    sub = int(z["sub"])
+    o, gn, cn = out.cpu().numpy(), g.cpu().numpy(), c.cpu().numpy()
+    for got, want in ((gn[:, :, ::sub, ::sub], z["guidance_sub"]), (cn[:, :, ::sub, ::sub], z["coarse_sub"]),
+                      (o[:, :, ::sub, ::sub], z["out_sub"])):
+        scale = float(np.abs(want).max())
+        assert float(np.abs(got - want).max()) <= 2e-3 * scale          # ~170 stacked fp32 convolutions, MIOpen vs oneDNN
+    # the hot path itself, on the tensors this network hands it: tight
+    want = c_oracle.cspn3_forward(gn, cn, s.cpu().numpy(), 24)
+    assert rel_err(o, want) <= 1e-5 and rmse(o, want) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_training_step_cspn_pair_and_gradients_match_oracle(c_oracle):
+    """One optimiser step at config 5's per-GPU shape (B=3, 228x304): capture what the network hands the CSPN module and
+    what flows back, and hold both against the oracle (forward 1e-5, gradients vs fp64)."""
+    from cspn_monodepth_amd.network import unet_cspn_nyu as net
+    torch.manual_seed(1)
+    m = net.resnet50(reference_state_dict=False).cuda().train()
+    m.return_cspn_io = True
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9)
+    B, H, W = 3, 228, 304
+    depth = torch.rand(B, 1, H, W, device="cuda") * 9.5 + 0.5
+    sparse = depth * (torch.rand(B, 1, H, W, device="cuda") < 500.0 / (H * W))
+    x = torch.cat([torch.rand(B, 3, H, W, device="cuda"), sparse], 1)
+    out, (g, c, s) = m(x)
+    g.retain_grad(); c.retain_grad(); out.retain_grad()
+    loss = (depth - out).abs().mean()
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    before = m.gud_up_proj_layer6.conv1.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.gud_up_proj_layer6.conv1.weight)      # the affinity head learns through the HIP backward
+    gn, cn, sn = (t.detach().cpu().numpy() for t in (g, c, s))
+    want = c_oracle.cspn3_forward(gn, cn, sn, 24)
+    assert rel_err(out.detach().cpu().numpy(), want) <= 1e-5
+    wg, wd = c_oracle.cspn3_backward(gn, cn, sn, out.grad.cpu().numpy(), 24, np.float64)
+    close = lambda a, b, tol: float(np.abs(a - b).max()) <= tol * max(float(np.abs(b).max()), 1e-30)   # noqa: E731
+    assert close(g.grad.cpu().numpy(), wg, 5e-4) and close(c.grad.cpu().numpy(), wd, 5e-5)
+    assert "libcspn_hip.so" in open("/proc/self/maps").read()

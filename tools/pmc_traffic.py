@@ -32,7 +32,10 @@ for d in sorted(glob.glob(os.path.join(root, wl + "_*"))):
         for (k, c), (tot, n) in acc.items():
             res[sched][k][c] = tot / n
             res[sched][k]["_dispatches_" + c] = n
-out = {"workload": wl, "per_kernel": res}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cspn_monodepth_amd import _lib as _cl   # noqa: E402  (source digest only; nothing is launched)
+out = {"workload": wl, "per_kernel": res, "source_digest": _cl._source_digest([]),
+       "commit": os.environ.get("CSPN_COMMIT", "")}
 for sched in res:
     for k, v in res[sched].items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
