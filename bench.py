@@ -95,7 +95,7 @@ def load_pmc_traffic(tag):
     except Exception:
         out["stale"] = None
     pk = j.get("per_kernel", {})
-    fused = [(k, v) for k, v in pk.get("fused", {}).items() if k.startswith("cspn_prop") and "hbm_bytes_corrected" in v]
+    fused = [(k, v) for k, v in pk.get("fused", {}).items() if k.startswith(("cspn_prop", "cspn3_resident")) and "hbm_bytes_corrected" in v]
     if fused:
         n_fwd = min(v["_dispatches_FETCH_SIZE"] for _, v in fused)       # every instance runs >= once per forward
         out["fused_per_launch"] = {k: v["hbm_bytes_corrected"] for k, v in fused}
@@ -384,9 +384,21 @@ def main():
                                        target[:, 0].contiguous(), pkg.evaluation.new_accumulator(device)))
             del w_
         module.plan = plan
+    if world > n_dev:
+        F.set_resident("off")      # several ranks share one GPU (gloo dry run): resident launches must own the device
     w_torch_dtype = torch.float16 if wl["dtype"] == "f16" else torch.float32
     eff_plan = F.resolve_plan(K, B_local, wl["H"], wl["W"], T, False,
                               plan if K == 3 else F.dtype_default_plan(K, w_torch_dtype, plan))
+    # which schedule will the step run?  (the weight-resident single launch serves the no-grad 3x3 calls it fits)
+    res_plan = None
+    if K == 3 and B_local > 0:
+        res_plan = F.resident_supported(g, d[:, 0], None if s is None else s[:, 0], T, plan,
+                                        None if args.no_metrics else target[:, 0])
+    if res_plan is not None:
+        eff_plan = dict(res_plan, schedule="resident", steps_per_launch=T)
+        eff_plan.pop("debug_stamps", None)
+    else:
+        eff_plan = dict(eff_plan, schedule="multi-launch")
     sums = pkg.evaluation.new_accumulator(device)
 
     if K == 3:
@@ -551,7 +563,9 @@ def main():
     # plane, + the target plane the fused metrics read)
     compulsory = B_local * wl["H"] * wl["W"] * ((K * K - 1) * esz_g + 2 * esz + (esz if args.sparse else 0) +
                                                 (0 if args.no_metrics else esz))
-    fused = {"kernel": "cspn_prop_fused<%d,...> S=%d (%d launches per forward)" % (K, S, launches_fwd),
+    fused = {"kernel": ("cspn3_resident<%d,...> (ONE launch, weights resident in VGPRs for all %d steps, %d-step phases)" % (
+                 eff_plan["quads_per_thread"], T, eff_plan["steps_per_phase"])) if res_plan is not None else
+             "cspn_prop_fused<%d,...> S=%d (%d launches per forward)" % (K, S, launches_fwd),
              "bound": "valu+lds (temporal blocking: the step loop runs out of LDS/VGPRs, HBM traffic is below the "
                       "algorithmic bytes)" if S > 1 else "hbm",
              "steps_per_launch": S, "launches_per_forward": launches_fwd,

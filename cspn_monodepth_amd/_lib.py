@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
@@ -27,7 +27,7 @@ BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
     "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn_propagate_transposed", "cspn3_propagate_from_guidance",
-    "cspn_transpose_weights",
+    "cspn_transpose_weights", "cspn3_resident_plan", "cspn3_resident_workspace_bytes", "cspn3_forward_resident",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
     "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
@@ -37,6 +37,12 @@ EXPORTS = (
 class cspn_plan(ctypes.Structure):
     _fields_ = [("steps_per_launch", ctypes.c_int), ("tile_w", ctypes.c_int), ("tile_h", ctypes.c_int),
                 ("quads_per_thread", ctypes.c_int), ("threads", ctypes.c_int), ("force_scalar", ctypes.c_int)]
+
+
+class cspn_resident_plan(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("steps_per_phase", "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread",
+                                            "threads", "images_per_launch", "launches", "lds_bytes", "n_cu")] + \
+               [("region_over_tile", ctypes.c_float), ("spin_limit", ctypes.c_uint), ("debug_stamps", ctypes.c_void_p)]
 
 
 class cspn_conv_geometry(ctypes.Structure):
@@ -111,6 +117,11 @@ def _declare(lib):
     lib.cspn3_propagate_from_guidance.argtypes = [vp, ci, cl, cl, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci,
                                                   vp, vp, ci,
                                                   ctypes.POINTER(cspn_plan), vp]
+    lib.cspn3_resident_plan.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_resident_plan)]
+    lib.cspn3_resident_workspace_bytes.argtypes = [ci, ci, ci]
+    lib.cspn3_resident_workspace_bytes.restype = cs
+    lib.cspn3_forward_resident.argtypes = [vp, cl, cl, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci,
+                                           ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
@@ -129,7 +140,7 @@ def _declare(lib):
     lib.cspn_unpool2d_backward.argtypes = [vp, vp, ci, cl, ci, ci, ci, ci, ci, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes"):
+        if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes", "cspn3_resident_workspace_bytes"):
             fn.restype = ci
     return lib
 

@@ -1,0 +1,651 @@
+// cspn_resident.hip — the 3x3 inference forward as ONE launch with the weights RESIDENT in registers for all T steps.
+//
+// Reference path: network/libs/post_process/CSPN_new.py:26-92 (abs / shift / normalise once, then 24 x {8-way propagate,
+// blend}).  The multi-launch schedule of cspn_propagate.hip re-streams the 8 weight planes once per launch of S steps
+// (config 2: 53 MB written once, read twice = 160 of the 271 MB a forward moves).  Here a workgroup owns ONE tile for the
+// whole forward:
+//   * it derives the normalised weights of its tile + (S-1)-pixel halo from the raw guidance ONCE (same arithmetic as
+//     cspn3_prepare_kernel / the WSRC=1 launch, div8_shared_reciprocal) and keeps them in VGPRs: no weight volume exists;
+//   * the T steps run in phases of S steps on the depth tile in LDS (the step loop of cspn_prop_fused);
+//   * between phases the workgroups exchange their tile borders through a global scratch plane with DEVICE-SCOPE (sc1)
+//     stores / loads — coherent across the 8 XCDs' private L2s without any cache-wide write-back or invalidate — and a
+//     per-tile phase flag the 8 neighbouring tiles poll (point-to-point, no grid barrier).
+// HBM traffic of a forward drops to ~the compulsory 8 guidance planes + depth in / out (+ the border exchange).
+//
+// All workgroups of a launch must be co-resident (they wait for each other): the host launches at most one workgroup
+// per CU and every workgroup claims more than half a CU's LDS, images are chunked over several launches when a batch
+// needs more tiles than CUs.  The neighbour wait is bounded: on time-out (another tenant holding CUs for seconds) the
+// launch sets the abort / error words of its workspace, the remaining workgroups drain, and the host raises on the next
+// call instead of hanging (include/cspn_hip.h: cspn3_forward_resident).
+#include "cspn_common.hpp"
+
+#include <atomic>
+
+namespace {
+
+struct ResArgs {
+    const float* g;          // guidance [B,C>=8,H,W], channels 0..7 read in place
+    long g_bs, g_cs;
+    const float* d0;         // [B,H,W]
+    const float* sparse;     // [B,H,W] or null
+    float* out;              // [B,H,W]
+    float* xbuf;             // exchange planes [2][B,H,W] (workspace)
+    unsigned* flags;         // [B * tiles_per_img] phase flags (workspace, zero-initialised once)
+    unsigned* status;        // [0] abort word of the running launch chain, [1] sticky error word (workspace)
+    unsigned* host_err;      // optional host-mapped word that receives the error as well
+    unsigned seq;            // flag base of this call: a tile that finished phase p publishes seq + p + 1
+    const float* target;     // SCORE: [B,H,W]
+    double* macc;
+    int nslots;
+    int B, H, W, Wv, T, S;
+    int tw, th, tiles_x, tiles_y;
+    int wq, wr, hxw, hyw, dr, ls;
+    int b0, nb;              // images [b0, b0 + nb) are refined by this launch
+    unsigned spin_limit;
+    unsigned long long* dbg;  // developer probe: [grid][16] wall-clock stamps (100 MHz) per workgroup, or null
+};
+
+__device__ __forceinline__ void st4_dev(float* p, float a, float b, float c, float d) {
+    // two 8-byte device-scope stores (global_store_dwordx2 ... sc1): visible to every XCD once vmcnt drops
+    unsigned long long lo = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+    unsigned long long hi = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(c);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld4_dev(const float* p) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                       __uint_as_float((unsigned)(hi >> 32)));
+}
+__device__ __forceinline__ float ld1_dev(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int NQ, int NTHREADS, int BLEND, int SCORE>
+__global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
+    constexpr int R = 1, NT = 8, WIN = 6;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int wg_bad;
+
+    const int tid = threadIdx.x;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int tile = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int bl = tile / tiles_per_img;                 // image within this launch
+    const int trem = tile - bl * tiles_per_img;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int b = a.b0 + bl;
+    const int H = a.H, W = a.W;
+    const int y0 = ty * a.th, x0 = tx * a.tw;
+    const size_t HW = (size_t)H * W;
+    const size_t plane = (size_t)a.B * HW;
+    if (tid == 0) wg_bad = 0;
+    int n_stamp = 0;
+    auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
+    stamp();
+
+    const float* __restrict__ din0 = a.d0 + (size_t)b * HW;
+    const float* __restrict__ spg = BLEND ? a.sparse + (size_t)b * HW : nullptr;
+
+    // ---- ownership: strip (sx, sy) = NQ vertically consecutive quads of the weight region (tile + halo) -------------
+    const int wq = a.wq, wr = a.wr;
+    const int sy = tid / wq;
+    const int sx = tid - sy * wq;
+    const int r0 = sy * NQ;
+    const int xq = x0 - a.hxw + 4 * sx;
+    const int yq0 = y0 - a.hyw + r0;
+    const bool x_in = (xq >= 0) && (xq < a.Wv);
+    const int nval = a.Wv - xq;
+    const int lane = tid & 63;
+    const bool fix_left = (sx == 0) || (lane == 0);
+    const bool fix_right = (sx == wq - 1) || (lane == 63);
+
+    // ---- 0. the coarse-depth region of phase 0 is requested FIRST: loads return in order, so it lands in LDS while the
+    //         (8x larger) guidance stream below is still in flight, and the staging costs no round trip of its own
+    const int dr = a.dr, ls = a.ls;
+    float* cur = lds;
+    float* nxt = lds + (size_t)dr * ls;
+    const int yd0 = y0 - a.hyw - R;            // image y of depth-region row 0
+    const int xd0 = x0 - a.hxw - 4;            // image x of LDS column 0
+    float4 st0[NQ + 1];                        // dr * wq <= (NQ + 1) * NTHREADS quads
+    int at0[NQ + 1];
+    unsigned st0_in = 0;
+#pragma unroll
+    for (int u = 0; u <= NQ; ++u) {
+        const int idx = u * NTHREADS + tid;
+        const int row = idx / wq, qx = idx - row * wq;
+        const int y = yd0 + row, x = xd0 + 4 + 4 * qx;
+        const bool valid = idx < dr * wq;
+        const bool in = valid && (y >= 0 && y < H && x >= 0 && x < a.Wv);
+        if (in) st0_in |= 1u << u;
+        st0[u] = ld4(din0 + (in ? (unsigned)(y * W + x) : 0u));
+        at0[u] = valid ? row * ls + 4 + 4 * qx : -1;
+    }
+    float ring0 = 0.f;
+    int ring0_at = -1;
+    bool ring0_in = false;
+    if (tid < dr * 2 * R) {
+        const int row = tid / (2 * R), c = tid - row * (2 * R);
+        const int lc = (c < R) ? (4 - R + c) : (4 + 4 * wq + (c - R));
+        const int y = yd0 + row, x = xd0 + lc;
+        ring0_in = (y >= 0 && y < H && x >= 0 && x < a.Wv);
+        ring0 = ld1(din0 + (ring0_in ? (unsigned)(y * W + x) : 0u));
+        ring0_at = row * ls + lc;
+    }
+
+    // ---- 1. weights of the owned quads, derived once from the raw guidance (CSPN_new.py:29-70, :124-127) -------------
+    float wreg[NQ][NT][4];
+    unsigned in_img = 0, interior = 0;
+    float* const md_lds = lds + (size_t)2 * a.dr * a.ls;          // private slots: m * d0 of the owned quads
+    const float* __restrict__ gq = a.g + (size_t)b * a.g_bs;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j: the aligned quad of row y+dy gives three of
+    // the four shifted values, the fourth is the neighbouring lane's quad (DPP) or, at strip ends / wave edges, a scalar.
+    // All loads are branch-free (safe address + select: a conditional load becomes its own basic block with its own wait)
+    // and are requested for every owned quad before the arithmetic starts.
+    // (32-bit element offsets from the image's guidance base: the loads take the SGPR-base + VGPR-offset form and cost no
+    // 64-bit address arithmetic; the host refuses guidance images of >= 2^30 elements.  Loads return in order, so quad i's
+    // scalars are requested right behind quad i's planes and the arithmetic below can start on quad 0 while quads 1.. stream.)
+    float edge[NQ][6];                     // [0..2]: column xq-1 of the dx<0 taps (j = 0,3,5); [3..5]: column xq+4 of the dx>0 taps (j = 2,4,7)
+    const unsigned ucs = (unsigned)a.g_cs;
+    unsigned edge_ok = 0;                  // bit i*6+t: edge[i][t] holds a pixel inside the image
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int r = r0 + i, y = yq0 + i;
+        const bool ok = (r < wr) && x_in && (y >= 0) && (y < H);
+        if (ok) in_img |= 1u << i;
+        if (ok && r >= a.hyw && r < a.hyw + a.th && xq >= x0 && xq < x0 + a.tw) interior |= 1u << i;
+        unsigned orow[3];
+        bool rokv[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int row = y + d - 1;
+            rokv[d] = ok && row >= 0 && row < H;
+            orow[d] = rokv[d] ? (unsigned)(row * W + xq) : 0u;   // outside the image: a safe address of the plane, zeroed below
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int d = lin / 3;
+            const float4 v = ld4(gq + ((unsigned)(7 - j) * ucs + orow[d]));
+            wreg[i][j][0] = rokv[d] ? v.x : 0.f; wreg[i][j][1] = rokv[d] ? v.y : 0.f;
+            wreg[i][j][2] = rokv[d] ? v.z : 0.f; wreg[i][j][3] = rokv[d] ? v.w : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) edge[i][t] = 0.f;
+        if (fix_left || fix_right) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const bool lft = t < 3;
+                const int j = lft ? (t == 0 ? 0 : (t == 1 ? 3 : 5)) : (t == 3 ? 2 : (t == 4 ? 4 : 7));
+                const int lin = j < 4 ? j : j + 1;
+                const int d = lin / 3;
+                const int xx = lft ? xq - 1 : xq + 4;
+                const bool c = rokv[d] && (lft ? fix_left : fix_right) && xx >= 0 && xx < W;
+                if (c) edge_ok |= 1u << (i * 6 + t);
+                // raw value only: consuming it here would make this block wait for the quad's loads (in-order return)
+                edge[i][t] = ld1(gq + ((unsigned)(7 - j) * ucs + (c ? orow[d] + (unsigned)(xx - xq) : 0u)));
+            }
+        }
+    }
+    // park the depth region (its loads were requested before the guidance: only those are waited for here)
+#pragma unroll
+    for (int u = 0; u <= NQ; ++u) {
+        const bool in = (st0_in >> u) & 1u;
+        if (at0[u] >= 0)
+            *reinterpret_cast<float4*>(&cur[at0[u]]) = make_float4(in ? st0[u].x : 0.f, in ? st0[u].y : 0.f, in ? st0[u].z : 0.f, in ? st0[u].w : 0.f);
+    }
+    if (ring0_at >= 0) { cur[ring0_at] = ring0_in ? ring0 : 0.f; nxt[ring0_at] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int r = r0 + i;
+        const bool ok = (in_img >> i) & 1u;
+        const size_t off = (size_t)(ok ? yq0 + i : 0) * W + (ok ? xq : 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int dx = lin % 3 - 1;
+            const float q0 = wreg[i][j][0], q1 = wreg[i][j][1], q2 = wreg[i][j][2], q3 = wreg[i][j][3];
+            if (dx < 0) {
+                const int t = j == 0 ? 0 : (j == 3 ? 1 : 2);
+                const float nb = dpp_from_prev_lane(q3);
+                const float lf = fix_left ? (((edge_ok >> (i * 6 + t)) & 1u) ? edge[i][t] : 0.f) : nb;
+                wreg[i][j][0] = fabsf(lf); wreg[i][j][1] = fabsf(q0); wreg[i][j][2] = fabsf(q1); wreg[i][j][3] = fabsf(q2);
+            } else if (dx > 0) {
+                const int t = j == 2 ? 3 : (j == 4 ? 4 : 5);
+                const float nb = dpp_from_next_lane(q0);
+                const float rt = fix_right ? (((edge_ok >> (i * 6 + t)) & 1u) ? edge[i][t] : 0.f) : nb;
+                wreg[i][j][0] = fabsf(q1); wreg[i][j][1] = fabsf(q2); wreg[i][j][2] = fabsf(q3); wreg[i][j][3] = fabsf(rt);
+            } else {
+                wreg[i][j][0] = fabsf(q0); wreg[i][j][1] = fabsf(q1); wreg[i][j][2] = fabsf(q2); wreg[i][j][3] = fabsf(q3);
+            }
+        }
+        // S in the reference's channel order k = 0..7 (tap 7..0), one shared refined reciprocal; 0 for padding quads
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float S = wreg[i][7][e];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) S += wreg[i][7 - k][e];
+            float av[8], qv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = wreg[i][j][e];
+            div8_shared_reciprocal(av, S, qv);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? qv[j] : 0.f;
+        }
+        if (BLEND && r < wr) {
+            // (1-m) u + m d0  ==  sum_j ((1-m) w_j) d_j + m d0 with 1-m in {0,1,2}: exact, so bit-identical (CSPN_new.py:90)
+            const float4 mraw = ld4(spg + off);                   // off = 0 for quads outside the image
+            const float4 m = make_float4(ok ? sgnf(mraw.x) : 0.f, ok ? sgnf(mraw.y) : 0.f, ok ? sgnf(mraw.z) : 0.f, ok ? sgnf(mraw.w) : 0.f);
+            const float omq[4] = {1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w};
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wreg[i][j][e] *= omq[e];
+            const float4 v = ld4(din0 + off);
+            *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) =
+                make_float4(ok ? m.x * v.x : 0.f, ok ? m.y * v.y : 0.f, ok ? m.z * v.z : 0.f, ok ? m.w * v.w : 0.f);
+        }
+    }
+
+    stamp();                                   // weights derived
+    // ---- 2. phases of S steps; between phases the tile borders travel through the exchange planes ---------------------
+    const bool active = (r0 < wr);
+    const int cb = 4 + 4 * sx;
+    float* __restrict__ dout = a.out + (size_t)b * HW;
+    const int n_phase = (a.T + a.S - 1) / a.S;
+    const int tile_global = b * tiles_per_img + trem;
+    float own[NQ][4];
+
+    for (int p = 0; p < n_phase; ++p) {
+        const int steps = (a.T - p * a.S) < a.S ? (a.T - p * a.S) : a.S;
+        const bool last_phase = (p == n_phase - 1);
+        // -- stage the depth region (weight region + 1 ring).  Phase 0: everything from the coarse depth.  Later phases:
+        //    the tile's own interior is already in LDS (`cur`), only the halo comes from the neighbours' published borders
+        const float* __restrict__ xin = a.xbuf + (size_t)((p + 1) & 1) * plane + (size_t)b * HW;   // written in phase p-1
+        if (p > 0) {
+            // halo quads only: (hyw + 1) full rows above and below the tile rows, hxw/4 quads left and right of them.  All
+            // device-scope loads of a batch are requested before the first one is consumed (branch-free: safe address + select).
+            const int hq = a.hxw >> 2;
+            const int nrow_tb = a.hyw + R;
+            const int n_top = nrow_tb * wq;
+            const int n_side = a.th * 2 * hq;
+            const int n_halo = 2 * n_top + n_side;
+            // the 1-pixel ring columns left / right of the region: one scalar per row and side
+            float ring_v = 0.f;
+            int ring_at = -1;
+            if (tid < dr * 2 * R) {
+                const int row = tid / (2 * R), c = tid - row * (2 * R);
+                const int lc = (c < R) ? (4 - R + c) : (4 + 4 * wq + (c - R));
+                const int y = yd0 + row, x = xd0 + lc;
+                const bool in = (y >= 0 && y < H && x >= 0 && x < a.Wv);
+                const float v = ld1_dev(xin + (in ? (size_t)y * W + x : (size_t)0));
+                ring_v = in ? v : 0.f;
+                ring_at = row * ls + lc;
+            }
+            for (int base = 0; base < n_halo; base += 2 * NTHREADS) {
+                float4 hv[2];
+                int at[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int h = base + u * NTHREADS + tid;
+                    int row, qx;
+                    if (h < n_top) { row = h / wq; qx = h - row * wq; }
+                    else if (h < 2 * n_top) { const int h2 = h - n_top; row = h2 / wq; qx = h2 - row * wq; row += nrow_tb + a.th; }
+                    else { const int h3 = h - 2 * n_top; row = h3 / (2 * hq); const int c = h3 - row * (2 * hq); row += nrow_tb; qx = c < hq ? c : wq - 2 * hq + c; }
+                    const int y = yd0 + row, x = xd0 + 4 + 4 * qx;
+                    const bool valid = h < n_halo;
+                    const bool in = valid && y >= 0 && y < H && x >= 0 && x < a.Wv;
+                    const float4 v = ld4_dev(xin + (in ? (size_t)y * W + x : (size_t)0));
+                    hv[u] = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+                    at[u] = valid ? row * ls + 4 + 4 * qx : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (at[u] >= 0) *reinterpret_cast<float4*>(&cur[at[u]]) = hv[u];
+            }
+            if (ring_at >= 0) { cur[ring_at] = ring_v; nxt[ring_at] = 0.f; }
+        }
+        __syncthreads();
+
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                int drow = r0 + i + R;
+                if (NQ > 1) drow = drow < dr ? drow : dr - 1;
+                const v4f mid = *(lds_cv4f_ptr)(cur + drow * ls + cb);
+                own[i][0] = mid.x; own[i][1] = mid.y; own[i][2] = mid.z; own[i][3] = mid.w;
+            }
+        }
+        // One propagation step on the LDS tile.  FINAL (the very last step of the forward) is peeled into its own copy so
+        // that the target quads of the fused metrics are only live there, not across the hot loop.
+        auto step = [&](auto final_c) __attribute__((always_inline)) {
+            constexpr bool FINAL = decltype(final_c)::value;
+            if (active) {
+                float win[NQ + 2 * R][WIN];
+                auto row_ptr = [&](int rr) -> const float* {
+                    int drow = r0 + rr;
+                    if (NQ > 1) drow = drow < dr ? drow : dr - 1;
+                    return cur + drow * ls + cb;
+                };
+#pragma unroll
+                for (int rr = 0; rr < NQ + 2 * R; ++rr) {
+                    float m4[4];
+                    if (rr >= R && rr < R + NQ) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) m4[c] = own[rr - R][c];
+                    } else {
+                        const v4f mid = *(lds_cv4f_ptr)(row_ptr(rr));
+                        m4[0] = mid.x; m4[1] = mid.y; m4[2] = mid.z; m4[3] = mid.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
+                    win[rr][0] = dpp_from_prev_lane(m4[3]);
+                    win[rr][5] = dpp_from_next_lane(m4[0]);
+                }
+                if (fix_left || fix_right) {       // one divergent block, all LDS scalars requested together
+#pragma unroll
+                    for (int rr = 0; rr < NQ + 2 * R; ++rr) {
+                        const float lv = row_ptr(rr)[-1], rv = row_ptr(rr)[4];
+                        win[rr][0] = fix_left ? lv : win[rr][0];
+                        win[rr][5] = fix_right ? rv : win[rr][5];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    if (r0 + i < wr) {
+                        float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                if (dy == 0 && dx == 0) continue;
+                                const int lin = (dy + 1) * 3 + (dx + 1);
+                                const int j = lin < 4 ? lin : lin - 1;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) u[e] = fmaf(wreg[i][j][e], win[i + dy + 1][e + dx + 1], u[e]);
+                            }
+                        if (BLEND) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(md_lds + ((r0 + i) * wq + sx) * 4);
+                            u[0] += m4.x; u[1] += m4.y; u[2] += m4.z; u[3] += m4.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((in_img >> i) & 1u) || e >= nval) u[e] = 0.f;       // zero padding stays exactly zero
+                        if (!FINAL)
+                            *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) = make_float4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) own[i][e] = u[e];
+                        if (FINAL && ((interior >> i) & 1u))
+                            st4(dout + (size_t)(yq0 + i) * W + xq, make_float4(u[0], u[1], u[2], u[3]));
+                    }
+                }
+            }
+            if (!FINAL) {
+                __syncthreads();
+                float* t = cur; cur = nxt; nxt = t;
+            }
+        };
+        stamp();                               // depth staged
+        const int plain_steps = last_phase ? steps - 1 : steps;
+        for (int s = 0; s < plain_steps; ++s) step(std::false_type{});
+        if (last_phase) step(std::true_type{});
+        stamp();                               // steps of the phase done
+        if (!last_phase) {
+            // -- publish the interior quads (device scope), then the phase flag; wait for the 8 neighbouring tiles
+            float* __restrict__ xout = a.xbuf + (size_t)(p & 1) * plane + (size_t)b * HW;
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    if ((interior >> i) & 1u) st4_dev(xout + (size_t)(yq0 + i) * W + xq, own[i][0], own[i][1], own[i][2], own[i][3]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's device-scope stores have landed
+            __syncthreads();                                       // ... and so have everybody else's in the workgroup
+            const unsigned want = a.seq + (unsigned)p + 1u;
+            if (tid == 0) __hip_atomic_store(a.flags + tile_global, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 9 && tid != 4) {
+                const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
+                    const unsigned* f = a.flags + b * tiles_per_img + ny * a.tiles_x + nx;
+                    unsigned spins = 0;
+                    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                        ++spins;
+                        if ((spins & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
+                            wg_bad = 1;
+                            break;
+                        }
+                        if (spins > a.spin_limit) {                // a neighbour never became resident / finished: give up
+                            __hip_atomic_store(a.status, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            wg_bad = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+            __syncthreads();
+            stamp();                           // neighbours' borders published
+            if (wg_bad) {
+                if (tid == 0) {
+                    __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return;
+            }
+        }
+    }
+    if (SCORE) {
+        float mf[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) mf[k] = 0.f;
+        if (active) {
+            // the target quads are requested only now: the weight registers are dead, nothing spills, and the one exposed
+            // round trip costs less than carrying NQ quads through the final step did
+            float4 scored_t[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const bool in = (interior >> i) & 1u;
+                scored_t[i] = ld4(a.target + (size_t)b * HW + (in ? (size_t)(yq0 + i) * W + xq : (size_t)0));
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if ((interior >> i) & 1u) {
+                    const float4 tg = scored_t[i];
+                    const float t4[4] = {tg.x, tg.y, tg.z, tg.w};
+                    const float o4[4] = {own[i][0], own[i][1], own[i][2], own[i][3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) metric_terms(o4[e], t4[e], mf);
+                }
+            }
+        }
+        float* part = lds + (size_t)2 * a.dr * a.ls + (size_t)(BLEND ? 1 : 0) * a.wr * 4 * a.wq;
+        const int wave = tid >> 6;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float v = wave_sum_to_lane63(mf[k]);
+            if (lane == 63) part[wave * 10 + k] = v;
+        }
+        __syncthreads();
+        if (tid < 10) {
+            double v = 0.0;
+            for (int w = 0; w < NTHREADS / 64; ++w) v += (double)part[w * 10 + tid];
+            if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + tid, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+constexpr int RES_THREADS = 512;
+constexpr int RES_MAX_NQ = 5;
+
+struct ResGeom {
+    int S, tiles_x, tiles_y, tw, th, nq, wq, wr, hxw, hyw, dr, ls;
+    int imgs_per_launch, launches;
+    size_t lds_bytes;
+    double cost;
+};
+
+int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cached[dev & 63].store(prop.multiProcessorCount, std::memory_order_relaxed);
+    return prop.multiProcessorCount;
+}
+
+// Tiling of one image for the resident kernel: every workgroup owns a tw x th tile + (S-1) halo; a launch holds
+// imgs_per_launch whole images on at most `ncu` workgroups.  Cost model: launches x (quads per thread + latency floor).
+bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_user, ResGeom* best) {
+    if (W % 4 != 0 || ncu < 1 || T < 1) return false;
+    bool found = false;
+    for (int S = (S_user > 0 ? S_user : 8); S >= (S_user > 0 ? S_user : 4); S -= 2) {
+        const int Se = S > T ? T : S;
+        const int hyw = Se - 1, hxw = round_up4(Se - 1);
+        const int phases = ceil_div(T, Se);
+        for (int tx = 1; tx <= 32; ++tx) {
+            const int tw = round_up4(ceil_div(W, tx));
+            if (tx > 1 && (tw < 16 || ceil_div(W, tw) != tx)) continue;
+            if (phases > 1 && tx > 1 && tw < hxw) continue;                       // halo must come from adjacent tiles only
+            const int wq = (tw + 2 * hxw) / 4;
+            if (wq > RES_THREADS) continue;
+            for (int ty = 1; ty <= 64; ++ty) {
+                const int th = ceil_div(H, ty);
+                if (ty > 1 && (th < 4 || ceil_div(H, th) != ty)) continue;
+                if (phases > 1 && ty > 1 && th < hyw) continue;
+                const int tiles = tx * ty;
+                if (tiles > ncu) continue;
+                const int wr = th + 2 * hyw;
+                const int rows_per_thread_col = RES_THREADS / wq;                 // strips per quad column
+                const int nq = ceil_div(wr, rows_per_thread_col);
+                if (nq > RES_MAX_NQ) continue;
+                const int dr = wr + 2, ls = 4 * wq + 8;
+                const size_t ldsb = ((size_t)2 * dr * ls + (size_t)(blend ? 1 : 0) * wr * 4 * wq + 16 * 10) * sizeof(float);
+                if (ldsb > 160 * 1024) continue;
+                int ipl = ncu / tiles;
+                if (ipl > B) ipl = B;
+                const int launches = ceil_div(B, ipl);
+                // per launch: derive (~2 steps' worth per quad) + T steps, each ~ (nq + 1.5) units; + exchange latency
+                const double cost = launches * ((T + 2.0) * (nq + 1.5) + 6.0 * (phases - 1));
+                if (!found || cost < best->cost) {
+                    found = true;
+                    *best = ResGeom{Se, tx, ty, tw, th, nq, wq, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, cost};
+                }
+            }
+        }
+    }
+    return found;
+}
+
+template <int NQ, int BLEND, int SCORE>
+int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
+    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, SCORE>;
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (lds_bytes > 64 * 1024 && granted[dev & 63].load(std::memory_order_acquire) < lds_bytes) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        granted[dev & 63].store(lds_bytes, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RES_THREADS), lds_bytes, st, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+template <int NQ>
+int launch_resident_nq(const ResArgs& a, int grid, size_t lds, int blend, bool score, hipStream_t st) {
+    if (blend) return score ? launch_resident_inst<NQ, 1, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0>(a, grid, lds, st);
+    return score ? launch_resident_inst<NQ, 0, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0>(a, grid, lds, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* out) {
+    if (!out || B < 1 || H < 1 || W < 1 || T < 0) return fail("cspn3_resident_plan: bad arguments");
+    if (n_cu <= 0) n_cu = cu_count();
+    if (n_cu <= 0) return fail("cspn3_resident_plan: no device (pass n_cu > 0 to plan without one)");
+    ResGeom g;
+    if (T < 1 || !resident_geometry(B, H, W, T, blend, n_cu, out->steps_per_phase, &g))
+        return fail("cspn3_resident_plan: no resident tiling for B=%d %dx%d T=%d on %d CUs (W %% 4 == 0 needed)", B, H, W, T, n_cu);
+    out->steps_per_phase = g.S; out->tiles_x = g.tiles_x; out->tiles_y = g.tiles_y; out->tile_w = g.tw; out->tile_h = g.th;
+    out->quads_per_thread = g.nq; out->threads = RES_THREADS; out->images_per_launch = g.imgs_per_launch;
+    out->launches = g.launches; out->lds_bytes = (int)g.lds_bytes; out->n_cu = n_cu;
+    out->region_over_tile = (float)((double)(4 * g.wq) * g.wr / ((double)g.tw * g.th));
+    return 1;
+}
+
+size_t cspn3_resident_workspace_bytes(int B, int H, int W) {
+    // 2 exchange planes, then 4 status words (abort, error, 2 reserved), then one flag per 16 pixels at most (tiles are >= 4 x 4)
+    const size_t planes = (size_t)2 * B * H * W * sizeof(float);
+    const size_t flags = ((size_t)B * (((size_t)H * W) / 16 + 1) + 4) * sizeof(unsigned);
+    return ((planes + 15) & ~(size_t)15) + ((flags + 15) & ~(size_t)15);
+}
+
+int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out,
+                           void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid, int T, int blend,
+                           const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
+                           cspn_stream_t stream) {
+    if (!guidance || !d0 || !out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1)
+        return fail("cspn3_forward_resident: bad arguments");
+    if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn3_forward_resident: blend %d", blend);
+    if (blend && !sparse) return fail("cspn3_forward_resident: blend needs sparse");
+    if ((target || acc) && (!target || !acc || nslots < 1 || !aligned16(target)))
+        return fail("cspn3_forward_resident: scoring needs target (16-byte aligned), acc and nslots >= 1");
+    if ((W & 3) || (cs & 3) || (bs & 3)) return fail("cspn3_forward_resident: W and the guidance strides must be multiples of 4");
+    if (cs < 0 || bs < 0 || cs >= (1L << 27) || (long)H * W >= (1L << 27))
+        return fail("cspn3_forward_resident: images of >= 2^27 pixels / channel strides >= 2^27 elements are not supported (32-bit offsets)");
+    if (!aligned16(guidance) || !aligned16(d0) || !aligned16(out) || !aligned16(work) || (sparse && !aligned16(sparse)))
+        return fail("cspn3_forward_resident: tensors must be 16-byte aligned");
+    if (W_valid < 0 || W_valid > W) return fail("cspn3_forward_resident: W_valid=%d outside (0, W=%d]", W_valid, W);
+    if (seq == 0 || seq > 0x7fffff00u) return fail("cspn3_forward_resident: seq must be in [1, 2^31 - 256]");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ncu = cu_count();
+    if (ncu <= 0) return fail("cspn3_forward_resident: no device");
+    ResGeom g;
+    cspn_resident_plan rp{};
+    if (plan) rp = *plan;
+    if (!resident_geometry(B, H, W, T, blend, ncu, rp.steps_per_phase, &g))
+        return fail("cspn3_forward_resident: no resident tiling for B=%d %dx%d T=%d", B, H, W, T);
+    ResArgs a{};
+    a.g = static_cast<const float*>(guidance); a.g_bs = bs; a.g_cs = cs;
+    a.d0 = static_cast<const float*>(d0); a.sparse = static_cast<const float*>(sparse); a.out = static_cast<float*>(out);
+    const size_t planes = (((size_t)2 * B * H * W * sizeof(float)) + 15) & ~(size_t)15;
+    a.xbuf = static_cast<float*>(work);
+    a.status = reinterpret_cast<unsigned*>(static_cast<char*>(work) + planes);   // fixed place, whatever the tiling
+    a.flags = a.status + 4;
+    if ((size_t)B * g.tiles_x * g.tiles_y > (size_t)B * (((size_t)H * W) / 16 + 1))
+        return fail("cspn3_forward_resident: workspace too small for %d tiles", B * g.tiles_x * g.tiles_y);
+    a.host_err = host_err;
+    a.seq = seq;
+    a.target = static_cast<const float*>(target); a.macc = acc; a.nslots = nslots;
+    a.B = B; a.H = H; a.W = W; a.Wv = (W_valid > 0 && W_valid < W) ? W_valid : W; a.T = T; a.S = g.S;
+    a.tw = g.tw; a.th = g.th; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+    a.wq = g.wq; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
+    a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);   // x (sc1 load + s_sleep) ~ seconds
+    a.dbg = rp.debug_stamps;
+    for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
+        a.b0 = b0;
+        a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
+        const int grid = a.nb * g.tiles_x * g.tiles_y;
+        int ok = 0;
+        switch (g.nq) {
+            case 1: ok = launch_resident_nq<1>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
+            case 2: ok = launch_resident_nq<2>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
+            case 3: ok = launch_resident_nq<3>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
+            case 4: ok = launch_resident_nq<4>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
+            case 5: ok = launch_resident_nq<5>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
+            default: return fail("cspn3_forward_resident: no instance for %d quads per thread", g.nq);
+        }
+        if (!ok) return 0;
+    }
+    return 1;
+}
+
+}  // extern "C"

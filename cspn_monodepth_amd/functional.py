@@ -8,6 +8,8 @@ path runs in libcspn_hip.so.  There is no CPU fallback.
 """
 import ctypes
 import math
+import os
+import threading
 
 import torch
 
@@ -483,6 +485,139 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
     return res + (w8, S_out) if return_weights else res
 
 
+# ------------------------------------------------------------------------------------------------ resident forward
+# cspn3_forward_resident (include/cspn_hip.h): ONE launch per chunk of whole images, weights resident in registers for
+# all T steps, tile borders exchanged between co-resident workgroups.  Its launches must not overlap on a device, so
+# this module serialises them: a lock around (order after the previous resident launch's stream, launch), per device.
+_RESIDENT_MODE = os.environ.get("CSPN_RESIDENT", "auto")      # "auto" | "on" | "off"
+_RES = {}                 # device index -> state dict
+_RES_LOCK = threading.Lock()
+_RES_SEQ_STEP = 8
+_RES_SEQ_MAX = (1 << 31) - 4096
+
+
+def set_resident(mode):
+    """"auto" (default): the weight-resident single-launch forward serves the no-grad 3x3 calls it fits and pays for;
+    "on": whenever it fits; "off": never (always the multi-launch schedule).  Results are bit-identical either way."""
+    global _RESIDENT_MODE
+    if mode not in ("auto", "on", "off"):
+        raise ValueError("set_resident: mode must be 'auto', 'on' or 'off'")
+    _RESIDENT_MODE = mode
+
+
+def resident_plan(B, H, W, T, blend=0, n_cu=0, steps_per_phase=0):
+    """The tiling cspn3_forward_resident would use (dict), or None when the shape has none (W % 4 != 0, T < 1, ...)."""
+    rp = _lib.cspn_resident_plan()
+    rp.steps_per_phase = int(steps_per_phase)
+    ok = _lib.lib().cspn3_resident_plan(int(B), int(H), int(W), int(T), int(blend), int(n_cu), ctypes.byref(rp))
+    if not ok:
+        return None
+    return {name: getattr(rp, name) for name, _ in _lib.cspn_resident_plan._fields_}
+
+
+def _resident_state(dev):
+    st = _RES.get(dev.index)
+    if st is None:
+        host_err = torch.zeros(4, dtype=torch.int32).pin_memory()
+        st = _RES[dev.index] = dict(seq=_RES_SEQ_STEP, work={}, host_err=host_err, host_err_np=host_err.numpy(),
+                                    last_stream=None, n_cu=torch.cuda.get_device_properties(dev).multi_processor_count)
+    return st
+
+
+def resident_pays(B, H, W, T, blend, dev):
+    """Policy of mode "auto": the resident launch needs enough tiles to occupy the chip (one workgroup per CU) and a
+    halo overhead that the saved weight passes pay for."""
+    rp = resident_plan(B, H, W, T, blend, _resident_state(dev)["n_cu"])
+    if rp is None:
+        return None
+    # measured on MI355X (tools/bench_resident.py, profiles/r02_resident_vs_multilaunch.txt): one resident launch beats
+    # the three-launch schedule by 10 % (config 2) to 35 % (B <= 3 shards); batches that need a second resident launch
+    # (more tiles than CUs) are a tie or slower, and those stay on the multi-launch schedule
+    if rp["launches"] > 1 or rp["region_over_tile"] > 3.6:
+        return None
+    return rp
+
+
+def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
+    """Can this no-grad 3x3 forward take the weight-resident launch?  (fp32, whole 16-byte quads, no explicit plan.)"""
+    if _RESIDENT_MODE == "off" or plan is not None or _DEFAULT_PLANS.get(3) is not None or T < 1:
+        return None
+    if guidance.dtype != torch.float32 or d0.dtype != torch.float32 or not from_guidance_supported(guidance, d0, sparse, None):
+        return None
+    if target is not None and (target.dtype != torch.float32 or target.data_ptr() % 16):
+        return None
+    B, H, W = d0.shape
+    if guidance.stride(1) >= (1 << 27) or H * W >= (1 << 27):
+        return None                                        # the kernel addresses an image with 32-bit element offsets
+    blend = int(sparse is not None)
+    dev = guidance.device
+    if _RESIDENT_MODE == "on":
+        return resident_plan(B, H, W, T, blend, _resident_state(dev)["n_cu"])
+    return resident_pays(B, H, W, T, blend, dev)
+
+
+def check_resident_errors(dev=None):
+    """Raise if a resident launch on `dev` (default: every device used so far) gave up waiting for a neighbouring tile —
+    i.e. its workgroups were not co-resident because something else held the GPU for seconds.  Called at the start of
+    every resident forward; the refined depth of the failed call is incomplete."""
+    for idx, st in list(_RES.items()):
+        if (dev is None or dev.index == idx) and st["host_err_np"][0] != 0:
+            st["host_err_np"][0] = 0
+            raise RuntimeError("cspn3_forward_resident on cuda:%d timed out waiting for a neighbouring tile (the GPU was "
+                               "shared with another long-running tenant, so the launch was not co-resident); the output of "
+                               "that call is incomplete.  Use cspn_monodepth_amd.functional.set_resident('off') or "
+                               "CSPN_RESIDENT=off when the device is shared." % idx)
+
+
+def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None):
+    """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it."""
+    dev = _require_device(guidance, d0, sparse)
+    B, C, H, W = guidance.shape
+    L = _lib.lib()
+    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    tg, acc = score if score is not None else (None, None)
+    rp = None
+    if steps_per_phase or spin_limit or debug_stamps is not None:
+        rp = _lib.cspn_resident_plan()
+        rp.steps_per_phase = int(steps_per_phase)
+        rp.spin_limit = int(spin_limit)
+        rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
+    log = _EVENT_LOG
+    with _RES_LOCK:
+        st = _resident_state(dev)
+        check_resident_errors(dev)
+        key = (B, H, W)
+        work = st["work"].get(key)
+        if work is None:
+            if len(st["work"]) > 16:
+                st["work"].clear()
+            work = st["work"][key] = torch.zeros((L.cspn3_resident_workspace_bytes(B, H, W),), dtype=torch.uint8, device=dev)
+        if st["seq"] > _RES_SEQ_MAX:                    # flag values wrap: start over on clean workspaces
+            for w_ in st["work"].values():
+                w_.zero_()
+            st["seq"] = _RES_SEQ_STEP
+        seq = st["seq"]
+        st["seq"] = seq + _RES_SEQ_STEP
+        with _device_guard(dev):
+            cur = torch.cuda.current_stream(dev)
+            last = st["last_stream"]
+            if last is not None and last != cur:
+                cur.wait_stream(last)                   # resident launches never overlap on a device
+            st["last_stream"] = cur
+            if log is not None:
+                ev0, ev1 = log.pair()
+                ev0.record(cur)
+            ok = L.cspn3_forward_resident(_p(guidance), guidance.stride(0), guidance.stride(1), _p(d0), _p(sparse), _p(out),
+                                          _p(work), seq, ctypes.c_void_p(st["host_err"].data_ptr()), B, H, W, int(valid_w),
+                                          int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
+                                          None if rp is None else ctypes.byref(rp), _stream(dev))
+            if log is not None:
+                ev1.record(cur)
+                log.append((ev0, ev1, 1, int(T)))
+    _lib.check(ok, "cspn3_forward_resident")
+    return out
+
+
 def transpose_weights(w, K, H, W):
     dev = _require_device(w)
     B = w.shape[0]
@@ -563,6 +698,9 @@ class CSPN3Function(torch.autograd.Function):
             raise TypeError("guidance / blur_depth / sparse_depth must share one dtype")
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
+        if not need_grad and resident_supported(guidance, d0, sp, prop_time, plan) is not None:
+            # inference, weight-resident: one launch for all T steps, no tap volume at all
+            return forward_resident(guidance, d0, sp, prop_time, blend, valid_w=valid_w).unsqueeze(1)
         if not need_grad and _FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan):
             # inference: no separate prepare pass (the first launch derives and publishes the weights)
             out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, valid_w=valid_w)
@@ -700,6 +838,9 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
     tg = _plane(target, B, H, W, "target")
     blend = BLEND_SPARSE if sp is not None else BLEND_NONE
     with torch.no_grad():
+        if guidance.dtype == d0.dtype == tg.dtype and resident_supported(guidance, d0, sp, prop_time, plan, tg) is not None:
+            out = forward_resident(guidance, d0, sp, prop_time, blend, score=(tg, acc), valid_w=vw)
+            return out.unsqueeze(1)[..., :W0]
         if (_FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan) and guidance.dtype == d0.dtype
                 and tg.dtype == d0.dtype and tg.data_ptr() % 16 == 0):
             p = resolve_plan(3, B, H, W, prop_time, False, plan)

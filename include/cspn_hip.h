@@ -214,6 +214,42 @@ typedef struct cspn_conv_geometry {
 /* Output extent for an input extent under `geom` (pac.py:41-42); writes Ho, Wo; 0 if the result is empty/invalid. */
 int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int* Wo);
 
+/* ---- weight-resident single-launch 3x3 forward (inference; CSPN_new.py:26-92) ------------------------------------------
+ * One launch per chunk of whole images: every workgroup owns one tile for all T steps, derives its normalised weights
+ * from the raw guidance once and keeps them in registers (no tap volume is written or re-read), runs the steps in phases
+ * of `steps_per_phase` on the depth tile in LDS and swaps tile borders with its 8 neighbouring tiles between phases
+ * through two scratch planes (device-scope stores/loads + one phase flag per tile).  Results are bit-identical to
+ * cspn3_propagate_from_guidance.  fp32, W % 4 == 0 (W_valid for narrower images), 16-byte aligned tensors.
+ *
+ * Co-residency: the workgroups of a launch wait for each other, so a launch never has more workgroups than the device
+ * has CUs (cspn3_resident_plan chunks the batch).  The device must not be shared with ANOTHER resident launch at the
+ * same time (a second process on the GPU, or a second stream of this process): callers serialise resident launches per
+ * device (cspn_monodepth_amd/functional.py chains them with events).  The neighbour wait is bounded (seconds): on
+ * time-out the launch stores 1 to status word 1 of the workspace (and to *host_err, a host-mapped word, if given),
+ * drains, and leaves `out` incomplete — the caller must check the word before trusting later results.
+ *
+ * work: cspn3_resident_workspace_bytes(B,H,W) bytes, ZERO-initialised once by the caller, then only ever passed to this
+ * entry.  seq: any value in [1, 2^31-256] that grows by at least 8 from one call on the same workspace to the next. */
+typedef struct cspn_resident_plan {
+    int steps_per_phase;   /* in: 0 = choose (8, stepping down to 4); out: the value used                  */
+    int tiles_x, tiles_y;  /* tiles per image                                                             */
+    int tile_w, tile_h;
+    int quads_per_thread, threads;
+    int images_per_launch, launches;
+    int lds_bytes, n_cu;
+    float region_over_tile; /* (tile + halo) area / tile area: the redundant-compute factor of the phases  */
+    unsigned spin_limit;    /* in: polls before a neighbour wait gives up; 0 = default (~seconds)          */
+    unsigned long long* debug_stamps; /* in: developer probe, device buffer [workgroups][16] of 100 MHz wall-clock stamps
+                                       * (start, weights derived, then per phase: staged, steps done, exchanged) or NULL */
+} cspn_resident_plan;
+/* n_cu <= 0: ask the current device.  Returns 0 (with a message) when no tiling fits. */
+int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
+size_t cspn3_resident_workspace_bytes(int B, int H, int W);
+int cspn3_forward_resident(const void* guidance, long g_batch_stride, long g_chan_stride, const void* d0,
+                           const void* sparse_or_null, void* out, void* work, unsigned seq, unsigned* host_err_or_null,
+                           int B, int H, int W, int W_valid, int T, int blend, const void* target_or_null,
+                           double* acc_or_null, int nslots, const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
+
 /* A/B + test switch (process-wide): on != 0 makes every cspn_pac_* entry skip its LDS-tiled kernels and run the generic
  * one-quad-per-thread kernels; the previous setting is stored to *previous_or_null.  The initial value is read once from
  * CSPN_PAC_SCALAR=1 in the environment (the hot path never calls getenv).  Results are identical either way. */

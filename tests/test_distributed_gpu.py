@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _torchrun(nproc, port, script_args, timeout=600):
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="4")
+    # several processes share the one GPU here: the weight-resident launches need the device to themselves (include/cspn_hip.h)
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="4", CSPN_RESIDENT="off")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port)] + script_args
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)

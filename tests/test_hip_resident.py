@@ -1,0 +1,156 @@
+"""GPU tests of the weight-resident single-launch forward (cspn3_forward_resident, csrc/cspn_resident.hip): one launch
+for all T steps, weights in registers, tile borders exchanged between co-resident workgroups.  It must give the SAME
+BITS as the multi-launch schedule (same weight arithmetic, same FMA order) and match the oracle / the reference goldens.
+
+Reference: network/libs/post_process/CSPN_new.py:26-92."""
+import numpy as np
+import pytest
+import torch
+
+import cspn_monodepth_amd as pkg
+from cspn_monodepth_amd import functional as F
+from conftest import golden_names, load_golden, rel_err, rmse
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+class resident(object):
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = F._RESIDENT_MODE
+        F.set_resident(self.mode)
+
+    def __exit__(self, *exc):
+        F.set_resident(self.prev)
+        return False
+
+
+def both(g, d, s, T):
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad():
+        with resident("off"):
+            ref = m(dev(g), dev(d), dev(s))
+        with resident("on"):
+            assert F.resident_supported(dev(g), dev(d)[:, 0], None if s is None else dev(s)[:, 0], T) is not None
+            out = m(dev(g), dev(d), dev(s))
+    torch.cuda.synchronize()
+    F.check_resident_errors()
+    return out, ref
+
+
+SHAPES = [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (8, 352, 1216, 24), (1, 228, 304, 24), (2, 13, 20, 24),
+          (5, 60, 64, 7), (2, 37, 8, 1), (1, 1, 12, 3), (3, 100, 148, 9), (1, 5, 4, 6), (30, 120, 160, 17)]
+
+
+@pytest.mark.parametrize("B,H,W,T", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_resident_equals_multi_launch_bit_for_bit(B, H, W, T, sparse, c_oracle):
+    g, d, s = c_oracle.synthetic_inputs(70 + B + T, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    out, ref = both(g, d, s, T)
+    assert torch.equal(out, ref)
+    if B * H * W <= 24 * 228 * 304:
+        want = c_oracle.cspn3_forward(g, d, s, T)
+        assert rel_err(out.cpu().numpy(), want) <= 1e-5 and rmse(out.cpu().numpy(), want) <= 1e-4
+
+
+@pytest.mark.parametrize("name", golden_names("g1_") + golden_names("g2_") + ["g8_unet_hook"])
+def test_resident_on_reference_goldens(name):
+    """Small / degenerate / NaN-spreading / negative-sparse cases captured from the reference, through the resident launch."""
+    z = load_golden(name)
+    if name == "g8_unet_hook":
+        g, d, s = (z[k].astype(np.float32) for k in ("guidance_f16", "blur_f16", "sparse_f16"))
+    else:
+        g, d, s = z["guidance"], z["blur"], z.get("sparse")
+    T = int(z["T"])
+    if g.shape[-1] % 4:                                   # odd widths: the module pads the rows and passes W_valid
+        m = pkg.CSPN_new.AffinityPropagate(T, 3)
+        with torch.no_grad(), resident("on"):
+            out = m(dev(g), dev(d), dev(s)).cpu().numpy()
+    else:
+        out = both(g, d, s, T)[0].cpu().numpy()
+    if name == "g8_unet_hook":
+        assert np.abs(out - z["out"]).max() <= 1e-6
+    else:
+        assert rel_err(out, z["out"]) <= 1e-5, name
+
+
+def test_resident_scored_and_phase_lengths(c_oracle):
+    """forward_scored through the resident launch = forward + metric sums; every steps-per-phase gives the same bits."""
+    ev = pkg.evaluation
+    B, H, W, T = 24, 228, 304, 24
+    g, d, s = c_oracle.synthetic_inputs(91, B, H, W, 12, 500)
+    tgt = np.maximum(d + 0.1 * c_oracle.hash_normal(92, 9, d.shape), 0.0).astype(np.float32)
+    tgt[c_oracle.hash_uniform(93, 9, d.shape) < 0.05] = 0.0
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    gt, dt, tt = dev(g), dev(d), dev(tgt)
+    for sp in (None, dev(s)):
+        with torch.no_grad():
+            with resident("off"):
+                acc0 = ev.new_accumulator(DEV)
+                ref = m.forward_scored(gt, dt, sp, tt, acc0)
+            with resident("on"):
+                acc1 = ev.new_accumulator(DEV)
+                out = m.forward_scored(gt, dt, sp, tt, acc1)
+        assert torch.equal(out, ref)
+        assert np.allclose(acc1.sum(0).cpu().numpy(), acc0.sum(0).cpu().numpy(), rtol=1e-6)
+        for S in (4, 6, 8):
+            with torch.no_grad():
+                o = F.forward_resident(gt, dt[:, 0], None if sp is None else sp[:, 0], T, int(sp is not None), steps_per_phase=S)
+            assert torch.equal(o, ref[:, 0]), S
+    F.check_resident_errors()
+
+
+def test_resident_launches_from_several_streams_are_serialised(c_oracle):
+    """Two host threads on two HIP streams: the module orders the resident launches after one another (they must
+    never overlap on a device); results equal the serial ones."""
+    import threading
+    B, H, W, T = 24, 228, 304, 24
+    cases = []
+    for i in range(2):
+        g, d, s = c_oracle.synthetic_inputs(95 + i, B, H, W, 12, 300)
+        cases.append((dev(g), dev(d), dev(s)))
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad(), resident("on"):
+        serial = [m(*c) for c in cases]
+        res = [None] * len(cases)
+
+        def work(i):
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(20):
+                    res[i] = m(*cases[i])
+            st.synchronize()
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    torch.cuda.synchronize()
+    F.check_resident_errors()
+    for a, b_ in zip(res, serial):
+        assert torch.equal(a, b_)
+
+
+def test_resident_timeout_is_loud_not_a_hang(c_oracle):
+    """A neighbour wait that gives up (spin limit forced to 1 poll) must end the launch and raise on the next call."""
+    B, H, W, T = 24, 228, 304, 24
+    g, d, _ = c_oracle.synthetic_inputs(99, B, H, W, 12, None)
+    gt, dt = dev(g), dev(d)[:, 0].contiguous()
+    with torch.no_grad():
+        F.forward_resident(gt, dt, None, T, 0, spin_limit=1)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
+            F.forward_resident(gt, dt, None, T, 0)
+        torch.cuda.synchronize()
+        out = F.forward_resident(gt, dt, None, T, 0)                   # the error was consumed; the path works again
+        with resident("off"):
+            ref = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dev(d))
+    assert torch.equal(out, ref[:, 0])
+    F.check_resident_errors()

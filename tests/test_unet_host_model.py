@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, rel_err, rmse
+from conftest import GOLDEN, load_golden, rmse
 
 
 def test_state_dict_matches_reference_keys_and_shapes():
@@ -71,8 +71,10 @@ def test_full_network_matches_reference_and_cspn_pair_matches_oracle(c_oracle):
         scale = float(np.abs(want).max())
         assert float(np.abs(got - want).max()) <= 2e-3 * scale          # ~170 stacked fp32 convolutions, MIOpen vs oneDNN
     # the hot path itself, on the tensors this network hands it: tight
+    # (an untrained head emits signed depths of ~1e-2 that cross zero, so the error is held against the value range —
+    # the same form as the G8 hook golden — not per pixel against |want| -> 0)
     want = c_oracle.cspn3_forward(gn, cn, s.cpu().numpy(), 24)
-    assert rel_err(o, want) <= 1e-5 and rmse(o, want) <= 1e-4
+    assert float(np.abs(o - want).max()) <= 1e-5 * float(np.abs(want).max()) and rmse(o, want) <= 1e-4
 
 
 @pytest.mark.gpu
@@ -98,7 +100,7 @@ def test_training_step_cspn_pair_and_gradients_match_oracle(c_oracle):
     assert not torch.equal(before, m.gud_up_proj_layer6.conv1.weight)      # the affinity head learns through the HIP backward
     gn, cn, sn = (t.detach().cpu().numpy() for t in (g, c, s))
     want = c_oracle.cspn3_forward(gn, cn, sn, 24)
-    assert rel_err(out.detach().cpu().numpy(), want) <= 1e-5
+    assert float(np.abs(out.detach().cpu().numpy() - want).max()) <= 1e-5 * float(np.abs(want).max())
     wg, wd = c_oracle.cspn3_backward(gn, cn, sn, out.grad.cpu().numpy(), 24, np.float64)
     close = lambda a, b, tol: float(np.abs(a - b).max()) <= tol * max(float(np.abs(b).max()), 1e-30)   # noqa: E731
     assert close(g.grad.cpu().numpy(), wg, 5e-4) and close(c.grad.cpu().numpy(), wd, 5e-5)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Developer tool: where does the resident launch spend its time?  T sweep at config 2 (derive / steps / exchanges)."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cspn_monodepth_amd import functional as F
+dev = "cuda:0"
+B, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (24, 228, 304)))
+g = torch.randn(B, 12, H, W, device=dev)
+d = (torch.rand(B, H, W, device=dev) * 10)
+for S in (8, 24):
+    for T in (1, 2, 4, 8, 9, 16, 17, 24):
+        if F.resident_plan(B, H, W, T, 0, 256, S) is None:
+            continue
+        with torch.no_grad():
+            for _ in range(5):
+                F.forward_resident(g, d, None, T, 0, steps_per_phase=S)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    F.forward_resident(g, d, None, T, 0, steps_per_phase=S)
+                e1.record(); e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / 30)
+        rp = F.resident_plan(B, H, W, T, 0, 256, S)
+        print("S=%d T=%2d: %.2f us  (nq %d, tiles %dx%d, region/tile %.2f)" % (S, T, best, rp["quads_per_thread"], rp["tiles_x"], rp["tiles_y"], rp["region_over_tile"]), flush=True)
+F.check_resident_errors()
