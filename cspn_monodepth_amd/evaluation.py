@@ -6,6 +6,10 @@ lg10, delta1, delta2, delta3) is kept.  The reference averages the per-GPU vecto
 in-process Reduce (network/libs/base/encoding.py:264-276), which is only right for equal valid-pixel
 counts; here every rank contributes additive masked *sums* + the count, gathered with one
 torch.distributed all_gather (RCCL over xGMI when the backend is "nccl"), then finalised.
+
+Deviation to know about: `finalize_metrics` is pixel-weighted over everything accumulated (one square root at the end).
+The reference's single-GPU eval loop prints the batch-size-weighted mean of PER-BATCH metrics (Result.evaluate +
+AverageMeter, libs/metrics.py:49-127) — `BatchAverageMeter` below reproduces exactly that for comparable numbers.
 """
 import ctypes
 import math
@@ -69,6 +73,42 @@ def finalize_metrics(sums):
     return dict(irmse=math.sqrt(s[0] / n), imae=s[1] / n, mse=mse, rmse=math.sqrt(mse), mae=s[3] / n,
                 absrel=s[4] / n, lg10=s[5] / n, delta1=s[6] / n, delta2=s[7] / n, delta3=s[8] / n,
                 count=int(round(n)))
+
+
+class BatchAverageMeter(object):
+    """The reference's averaging, for numbers comparable with its logs: `Result.evaluate` finalises the metrics PER BATCH
+    (libs/metrics.py:49-83: rmse = sqrt of that batch's mse, irmse likewise) and `AverageMeter` averages those per-batch
+    values weighted by the batch size n (libs/metrics.py:101-127, called with n = input.size(0) by the trainers).
+
+    `finalize_metrics` over accumulated sums is the pixel-weighted GLOBAL figure instead (one sqrt over all pixels):
+    the two agree for mse / mae / absrel / lg10 / delta only when every batch has the same valid-pixel count, and
+    never exactly for rmse / irmse (mean of square roots != square root of the mean).  Use this class to reproduce the
+    reference's printed averages; use the sums for the all-gathered multi-GPU figure.
+
+        meter = BatchAverageMeter()
+        for batch: meter.update(metric_sums(pred, target), n=pred.shape[0])      # one float64[10] per batch
+        meter.average()  ->  dict of the 10 metrics (+ 'count' = number of samples, as AverageMeter.count)"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.count = 0.0
+        self.sums = {k: 0.0 for k in METRIC_NAMES}
+
+    def update(self, batch_sums, n=1):
+        fin = finalize_metrics(batch_sums.cpu() if hasattr(batch_sums, "cpu") else batch_sums)
+        if fin["count"] == 0:            # the reference would record NaN for a batch without valid pixels; so do we
+            pass
+        self.count += n
+        for k in METRIC_NAMES:
+            self.sums[k] += n * fin[k]
+        return fin
+
+    def average(self):
+        if self.count <= 0:
+            return dict({k: float("nan") for k in METRIC_NAMES}, count=0)
+        return dict({k: self.sums[k] / self.count for k in METRIC_NAMES}, count=self.count)
 
 
 def all_gather_metric_sums(sums, group=None):

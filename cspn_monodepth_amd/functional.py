@@ -441,7 +441,11 @@ def from_guidance_supported(guidance, d0, sparse, plan=None):
 def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, plan=None, publish_weights=True,
                             score=None, valid_w=0, return_weights=False):
     """3x3 variant without a prepare pass: every launch derives the normalised weights from `guidance`
-    (cspn3_propagate_from_guidance).  Same results, bit for bit, as cspn3_prepare + propagate.
+    (cspn3_propagate_from_guidance).  fp32: same results, bit for bit, as cspn3_prepare + propagate, whatever the plan.
+    fp16 storage is plan-dependent by construction: the deriving launch uses the unrounded fp32 weights for its S steps
+    and keeps the state in fp32 inside a launch, later launches stream the fp16-rounded volume and the state is rounded
+    to half between launches — results differ by fp16 rounding (<= 4e-3 of the range, the tolerance of the fp16 tests)
+    between plans and from the prepare + propagate form.
 
     return_weights=True (the training forward) also returns the published tap volume and the normaliser S the
     first launch wrote: (d_T, history, w8, S)."""

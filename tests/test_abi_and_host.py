@@ -106,3 +106,34 @@ def test_widening_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.cspn_unpool2d(one, one, _lib.CSPN_F32, 4, 5, 6, 2, 11, 12, None) == 0 and "must lie in" in err()   # oH > 2*H
     assert L.cspn_unpool2d(one, one, _lib.CSPN_F32, 4, 5, 6, 0, 5, 6, None) == 0 and "scale" in err()
     assert L.cspn_unpool2d_backward(one, None, _lib.CSPN_F32, 4, 5, 6, 2, 10, 12, None) == 0 and "null" in err()
+
+
+def test_batch_average_meter_reproduces_reference_averaging():
+    """the reference's eval prints the batch-weighted mean of per-batch metrics (Result.evaluate +
+    AverageMeter, libs/metrics.py:49-127), not the pixel-weighted global figure.  Checked against the numpy oracle's
+    restatement of Result.evaluate (pinned by golden G7) on batches with unequal valid-pixel counts."""
+    import numpy as np
+    import torch
+    from cspn_monodepth_amd import evaluation as ev
+    from oracle import cspn_oracle as orc
+    rng = np.random.default_rng(3)
+    meter = ev.BatchAverageMeter()
+    want = np.zeros(10)
+    total = np.zeros(10)
+    n_tot = 0
+    for n, frac in ((1, 0.9), (3, 0.4), (2, 0.7)):
+        t = rng.uniform(0.5, 10, (n, 1, 12, 16)).astype(np.float32)
+        t[rng.random(t.shape) > frac] = 0
+        p = (np.abs(t + rng.normal(0, 0.3, t.shape)) + 0.05).astype(np.float32)
+        sums = orc.metric_sums(p, t)
+        meter.update(torch.from_numpy(sums), n=n)
+        ref, _ = orc.evaluate_metrics(p, t)                       # Result.evaluate of this batch
+        want += n * np.asarray(ref)
+        total += sums
+        n_tot += n
+    avg = meter.average()
+    assert avg["count"] == n_tot
+    for k, v in zip(ev.METRIC_NAMES, want / n_tot):
+        assert np.isclose(avg[k], v, rtol=1e-6), k
+    glob = ev.finalize_metrics(torch.from_numpy(total))
+    assert not np.isclose(glob["rmse"], avg["rmse"], rtol=1e-4)   # the two conventions really differ
