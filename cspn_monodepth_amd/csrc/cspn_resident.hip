@@ -12,11 +12,17 @@
 //     per-tile phase flag the 8 neighbouring tiles poll (point-to-point, no grid barrier).
 // HBM traffic of a forward drops to ~the compulsory 8 guidance planes + depth in / out (+ the border exchange).
 //
-// All workgroups of a launch must be co-resident (they wait for each other): the host launches at most one workgroup
-// per CU and every workgroup claims more than half a CU's LDS, images are chunked over several launches when a batch
-// needs more tiles than CUs.  The neighbour wait is bounded: on time-out (another tenant holding CUs for seconds) the
-// launch sets the abort / error words of its workspace, the remaining workgroups drain, and the host raises on the next
-// call instead of hanging (include/cspn_hip.h: cspn3_forward_resident).
+// All workgroups of a launch must be co-resident (they wait for each other): a launch never has more workgroups than the
+// device has CUs (every instance fits at least once per CU), images are chunked over several launches when a batch needs
+// more tiles than CUs.  The neighbour wait is bounded: on time-out (another tenant holding CUs for seconds) the launch
+// sets the abort / error words of its workspace, the remaining workgroups drain, and the host raises on the next call
+// instead of hanging (include/cspn_hip.h: cspn3_forward_resident).
+//
+// Measured on MI355X (config 2: B=24, 228x304, T=24; profiles/r02_*): 2x5 tiles of 152x46 per image = 240 workgroups of
+// 512 threads x 5 quads (160 weight registers per thread, 256 VGPRs), 8-step phases.  Timeline per workgroup: weights
+// derived 10.8 us (the 53 MB guidance stream, HBM-bound), 3 x 7.4 us of steps (VALU-bound: ~270 instructions per
+// wavefront-step at 2 wavefronts per SIMD), 2 x (4 us exchange + 1.7 us halo staging), fused metrics ~7 us: 58 us per
+// scored forward against 73.5 us for the three S=8 launches, with 2.3x less HBM traffic.
 #include "cspn_common.hpp"
 
 #include <atomic>
@@ -46,11 +52,11 @@ struct ResArgs {
 };
 
 __device__ __forceinline__ void st4_dev(float* p, float a, float b, float c, float d) {
-    // two 8-byte device-scope stores (global_store_dwordx2 ... sc1): visible to every XCD once vmcnt drops
-    unsigned long long lo = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
-    unsigned long long hi = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(c);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE 16-byte device-scope store (global_store_dwordx4 ... sc1): visible to every XCD once vmcnt drops.  Written as
+    // asm because the compiler only offers <= 8-byte atomics, and two 8-byte stores per quad touch every 64-byte line
+    // twice with half masks (PMC: 2x the written bytes).  The caller waits with s_waitcnt vmcnt(0) before it signals.
+    const v4f v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ float4 ld4_dev(const float* p) {
     const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,8 +99,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     const int sy = tid / wq;
     const int sx = tid - sy * wq;
     const int r0 = sy * NQ;
-    const int xq = x0 - a.hxw + 4 * sx;
-    const int yq0 = y0 - a.hyw + r0;
+    // Region origin: the tile's halo is laid out around it, but SHIFTED back into the image at image edges (a region that
+    // would stick out on one side extends further on the other instead).  With W >= 4 wq and H >= wr every owned quad then
+    // lies inside the image: no zero-padding selects in the step loop, no wasted halo, equal work for edge and inner tiles.
+    const int rx0 = max(0, min(x0 - a.hxw, W - 4 * wq));
+    const int ry0 = max(0, min(y0 - a.hyw, H - wr));
+    const int xq = rx0 + 4 * sx;
+    const int yq0 = ry0 + r0;
     const bool x_in = (xq >= 0) && (xq < a.Wv);
     const int nval = a.Wv - xq;
     const int lane = tid & 63;
@@ -106,8 +117,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     const int dr = a.dr, ls = a.ls;
     float* cur = lds;
     float* nxt = lds + (size_t)dr * ls;
-    const int yd0 = y0 - a.hyw - R;            // image y of depth-region row 0
-    const int xd0 = x0 - a.hxw - 4;            // image x of LDS column 0
+    const int yd0 = ry0 - R;                   // image y of depth-region row 0
+    const int xd0 = rx0 - 4;                   // image x of LDS column 0
     float4 st0[NQ + 1];                        // dr * wq <= (NQ + 1) * NTHREADS quads
     int at0[NQ + 1];
     unsigned st0_in = 0;
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         const int r = r0 + i, y = yq0 + i;
         const bool ok = (r < wr) && x_in && (y >= 0) && (y < H);
         if (ok) in_img |= 1u << i;
-        if (ok && r >= a.hyw && r < a.hyw + a.th && xq >= x0 && xq < x0 + a.tw) interior |= 1u << i;
+        if (ok && y >= y0 && y < y0 + a.th && xq >= x0 && xq < x0 + a.tw) interior |= 1u << i;
         unsigned orow[3];
         bool rokv[3];
 #pragma unroll
@@ -189,6 +200,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             }
         }
     }
+    // Wavefronts whose quads all lie inside the image (every wavefront, once the regions are shifted into an image that is
+    // at least one region large) run a step body without the zero-padding selects.
+    bool needs_pad = false;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if (r0 + i < wr && (!((in_img >> i) & 1u) || nval < 4)) needs_pad = true;
+    const bool wave_clean = __builtin_amdgcn_ballot_w64(needs_pad) == 0ull;
     // park the depth region (its loads were requested before the guidance: only those are waited for here)
 #pragma unroll
     for (int u = 0; u <= NQ; ++u) {
@@ -265,13 +283,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         //    the tile's own interior is already in LDS (`cur`), only the halo comes from the neighbours' published borders
         const float* __restrict__ xin = a.xbuf + (size_t)((p + 1) & 1) * plane + (size_t)b * HW;   // written in phase p-1
         if (p > 0) {
-            // halo quads only: (hyw + 1) full rows above and below the tile rows, hxw/4 quads left and right of them.  All
+            // halo quads only: the full rows above and below the tile rows, the quads left and right of the tile columns.  All
             // device-scope loads of a batch are requested before the first one is consumed (branch-free: safe address + select).
-            const int hq = a.hxw >> 2;
-            const int nrow_tb = a.hyw + R;
-            const int n_top = nrow_tb * wq;
-            const int n_side = a.th * 2 * hq;
-            const int n_halo = 2 * n_top + n_side;
+            const int tq_in = min(a.tw, rx0 + 4 * wq - x0) >> 2;   // tile columns / rows that lie inside the region (the last
+            const int th_in = min(a.th, ry0 + wr - y0);            // tile of an image may be cut short by the image edge)
+            const int nl = (x0 - rx0) >> 2;                    // quads left of the tile columns inside the region
+            const int nside = wq - tq_in;                      // ... left + right
+            const int nrow_t = (y0 - ry0) + R;                 // depth-region rows above the tile rows (ring row included)
+            const int n_top = nrow_t * wq;
+            const int n_bot = (dr - nrow_t - th_in) * wq;
+            const int n_side = th_in * nside;
+            const int n_halo = n_top + n_bot + n_side;
             // the 1-pixel ring columns left / right of the region: one scalar per row and side
             float ring_v = 0.f;
             int ring_at = -1;
@@ -292,8 +314,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     const int h = base + u * NTHREADS + tid;
                     int row, qx;
                     if (h < n_top) { row = h / wq; qx = h - row * wq; }
-                    else if (h < 2 * n_top) { const int h2 = h - n_top; row = h2 / wq; qx = h2 - row * wq; row += nrow_tb + a.th; }
-                    else { const int h3 = h - 2 * n_top; row = h3 / (2 * hq); const int c = h3 - row * (2 * hq); row += nrow_tb; qx = c < hq ? c : wq - 2 * hq + c; }
+                    else if (h < n_top + n_bot) { const int h2 = h - n_top; row = h2 / wq; qx = h2 - row * wq; row += nrow_t + th_in; }
+                    else {
+                        const int h3 = h - n_top - n_bot;
+                        const int ns = nside > 0 ? nside : 1;
+                        row = h3 / ns;
+                        const int c = h3 - row * ns;
+                        row += nrow_t;
+                        qx = c < nl ? c : c + tq_in;
+                    }
                     const int y = yd0 + row, x = xd0 + 4 + 4 * qx;
                     const bool valid = h < n_halo;
                     const bool in = valid && y >= 0 && y < H && x >= 0 && x < a.Wv;
@@ -320,8 +349,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         }
         // One propagation step on the LDS tile.  FINAL (the very last step of the forward) is peeled into its own copy so
         // that the target quads of the fused metrics are only live there, not across the hot loop.
-        auto step = [&](auto final_c) __attribute__((always_inline)) {
+        auto step = [&](auto final_c, auto clean_c) __attribute__((always_inline)) {
             constexpr bool FINAL = decltype(final_c)::value;
+            constexpr bool CLEAN = decltype(clean_c)::value;     // every quad of this wavefront lies inside the image
             if (active) {
                 float win[NQ + 2 * R][WIN];
                 auto row_ptr = [&](int rr) -> const float* {
@@ -344,13 +374,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     win[rr][0] = dpp_from_prev_lane(m4[3]);
                     win[rr][5] = dpp_from_next_lane(m4[0]);
                 }
-                if (fix_left || fix_right) {       // one divergent block, all LDS scalars requested together
+                // strip-end / wave-edge lanes patch their halo column from LDS: exec-masked ds_read straight into the window
+                // registers (a merged block with selects costs 28 v_mov per step and measured 7 % slower)
+                if (fix_left) {
 #pragma unroll
-                    for (int rr = 0; rr < NQ + 2 * R; ++rr) {
-                        const float lv = row_ptr(rr)[-1], rv = row_ptr(rr)[4];
-                        win[rr][0] = fix_left ? lv : win[rr][0];
-                        win[rr][5] = fix_right ? rv : win[rr][5];
-                    }
+                    for (int rr = 0; rr < NQ + 2 * R; ++rr) win[rr][0] = row_ptr(rr)[-1];
+                }
+                if (fix_right) {
+#pragma unroll
+                    for (int rr = 0; rr < NQ + 2 * R; ++rr) win[rr][5] = row_ptr(rr)[4];
                 }
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
@@ -370,9 +402,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                             const float4 m4 = *reinterpret_cast<const float4*>(md_lds + ((r0 + i) * wq + sx) * 4);
                             u[0] += m4.x; u[1] += m4.y; u[2] += m4.z; u[3] += m4.w;
                         }
+                        if (!CLEAN) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (!((in_img >> i) & 1u) || e >= nval) u[e] = 0.f;       // zero padding stays exactly zero
+                            for (int e = 0; e < 4; ++e)
+                                if (!((in_img >> i) & 1u) || e >= nval) u[e] = 0.f;   // zero padding stays exactly zero
+                        }
                         if (!FINAL)
                             *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) = make_float4(u[0], u[1], u[2], u[3]);
 #pragma unroll
@@ -389,8 +423,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         };
         stamp();                               // depth staged
         const int plain_steps = last_phase ? steps - 1 : steps;
-        for (int s = 0; s < plain_steps; ++s) step(std::false_type{});
-        if (last_phase) step(std::true_type{});
+        if (!BLEND && wave_clean) {        // (the sparse variant is at the 256-VGPR limit: a second copy of the step body made it spill)
+            for (int s = 0; s < plain_steps; ++s) step(std::false_type{}, std::true_type{});
+            if (last_phase) step(std::true_type{}, std::true_type{});
+        } else {
+            for (int s = 0; s < plain_steps; ++s) step(std::false_type{}, std::false_type{});
+            if (last_phase) step(std::true_type{}, std::false_type{});
+        }
         stamp();                               // steps of the phase done
         if (!last_phase) {
             // -- publish the interior quads (device scope), then the phase flag; wait for the 8 neighbouring tiles
@@ -511,13 +550,13 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
         for (int tx = 1; tx <= 32; ++tx) {
             const int tw = round_up4(ceil_div(W, tx));
             if (tx > 1 && (tw < 16 || ceil_div(W, tw) != tx)) continue;
-            if (phases > 1 && tx > 1 && tw < hxw) continue;                       // halo must come from adjacent tiles only
+            if (phases > 1 && tx > 1 && tw < 2 * hxw) continue;                   // the (shifted) halo must come from adjacent tiles only
             const int wq = (tw + 2 * hxw) / 4;
             if (wq > RES_THREADS) continue;
             for (int ty = 1; ty <= 64; ++ty) {
                 const int th = ceil_div(H, ty);
                 if (ty > 1 && (th < 4 || ceil_div(H, th) != ty)) continue;
-                if (phases > 1 && ty > 1 && th < hyw) continue;
+                if (phases > 1 && ty > 1 && th < 2 * hyw) continue;
                 const int tiles = tx * ty;
                 if (tiles > ncu) continue;
                 const int wr = th + 2 * hyw;

@@ -18,6 +18,11 @@
  *   - re-entrant: no global mutable state; the caller selects the device (hipSetDevice)
  *     before the call, as `with torch.cuda.device(...)` does at encoding.py:168.
  *
+ * Scope of the 3x3 entries: the reference's CSPN_new.AffinityPropagate is only meaningful for prop_kernel = 3 (with 5 its
+ * ones-kernel becomes 1x2x2 and the output silently shrinks to (H-1)x(W-1), CSPN_new.py:122); the host module raises
+ * for prop_kernel != 3 and K x K windows (K = 3, 5, 7) are served by the softmax / PAC entries (cspn_pac_prepare +
+ * cspn_propagate with K), which is what the reference's CSPN_ours module computes.
+ *
  * Tensor layout: NCHW contiguous planes.  "taps" are the K*K-1 non-centre offsets (dy,dx) in
  * row-major order over [-K/2, K/2]^2; tap j of a weight volume multiplies depth[p + off_j].
  *
