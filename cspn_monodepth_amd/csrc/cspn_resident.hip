@@ -102,8 +102,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // Region origin: the tile's halo is laid out around it, but SHIFTED back into the image at image edges (a region that
     // would stick out on one side extends further on the other instead).  With W >= 4 wq and H >= wr every owned quad then
     // lies inside the image: no zero-padding selects in the step loop, no wasted halo, equal work for edge and inner tiles.
-    const int rx0 = max(0, min(x0 - a.hxw, W - 4 * wq));
-    const int ry0 = max(0, min(y0 - a.hyw, H - wr));
+    // The shift never moves a region start before the previous tile's start, so that the halo always comes from the 8
+    // ADJACENT tiles (the ones the exchange waits for) — a last tile cut short by the image edge keeps some out-of-image
+    // rows / columns instead, and its wavefronts run the step body with the zero-padding selects.
+    const int rx0 = max(max(0, x0 - a.tw), min(x0 - a.hxw, W - 4 * wq));
+    const int ry0 = max(max(0, y0 - a.th), min(y0 - a.hyw, H - wr));
     const int xq = rx0 + 4 * sx;
     const int yq0 = ry0 + r0;
     const bool x_in = (xq >= 0) && (xq < a.Wv);
@@ -215,6 +218,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             *reinterpret_cast<float4*>(&cur[at0[u]]) = make_float4(in ? st0[u].x : 0.f, in ? st0[u].y : 0.f, in ? st0[u].z : 0.f, in ? st0[u].w : 0.f);
     }
     if (ring0_at >= 0) { cur[ring0_at] = ring0_in ? ring0 : 0.f; nxt[ring0_at] = 0.f; }
+    // The ring ROWS of the second buffer are never computed either.  With the regions shifted into the image they ARE the
+    // zero padding above / below the image for edge tiles, so they must read as exactly 0 in both buffers (LDS keeps
+    // whatever the previous kernel left there).
+    for (int c = tid; c < 2 * ls; c += NTHREADS) nxt[(c < ls ? 0 : (dr - 1) * ls - ls) + c] = 0.f;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int r = r0 + i;
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     if (at[u] >= 0) *reinterpret_cast<float4*>(&cur[at[u]]) = hv[u];
             }
             if (ring_at >= 0) { cur[ring_at] = ring_v; nxt[ring_at] = 0.f; }
+            for (int c = tid; c < 2 * ls; c += NTHREADS) nxt[(c < ls ? 0 : (dr - 1) * ls - ls) + c] = 0.f;   // see phase 0
         }
         __syncthreads();
 
@@ -650,8 +658,25 @@ int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d
     ResGeom g;
     cspn_resident_plan rp{};
     if (plan) rp = *plan;
-    if (!resident_geometry(B, H, W, T, blend, ncu, rp.steps_per_phase, &g))
+    if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
+        // a plan that came out of cspn3_resident_plan for this problem: re-derive the dependent fields and re-check the
+        // limits, skip the search (it is ~6000 candidate tilings: tens of microseconds per call on the host)
+        const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
+        g.S = Se; g.tiles_x = rp.tiles_x; g.tiles_y = rp.tiles_y; g.tw = rp.tile_w; g.th = rp.tile_h;
+        g.hyw = Se - 1; g.hxw = round_up4(Se - 1);
+        g.wq = (g.tw + 2 * g.hxw) / 4; g.wr = g.th + 2 * g.hyw;
+        g.dr = g.wr + 2; g.ls = 4 * g.wq + 8;
+        g.nq = g.wq > 0 && g.wq <= RES_THREADS ? ceil_div(g.wr, RES_THREADS / g.wq) : RES_MAX_NQ + 1;
+        g.lds_bytes = ((size_t)2 * g.dr * g.ls + (size_t)(blend ? 1 : 0) * g.wr * 4 * g.wq + 16 * 10) * sizeof(float);
+        g.imgs_per_launch = rp.images_per_launch;
+        const int phases = ceil_div(T, Se);
+        if ((g.tw & 3) || g.nq > RES_MAX_NQ || g.lds_bytes > 160 * 1024 || g.tiles_x * g.tw < W || g.tiles_y * g.th < H ||
+            (long)g.imgs_per_launch * g.tiles_x * g.tiles_y > ncu ||
+            (phases > 1 && ((g.tiles_x > 1 && g.tw < 2 * g.hxw) || (g.tiles_y > 1 && g.th < 2 * g.hyw))))
+            return fail("cspn3_forward_resident: the plan does not fit this problem / device (use cspn3_resident_plan)");
+    } else if (!resident_geometry(B, H, W, T, blend, ncu, rp.steps_per_phase, &g)) {
         return fail("cspn3_forward_resident: no resident tiling for B=%d %dx%d T=%d", B, H, W, T);
+    }
     ResArgs a{};
     a.g = static_cast<const float*>(guidance); a.g_bs = bs; a.g_cs = cs;
     a.d0 = static_cast<const float*>(d0); a.sparse = static_cast<const float*>(sparse); a.out = static_cast<float*>(out);

@@ -528,16 +528,37 @@ def _resident_state(dev):
     return st
 
 
+_RES_PLAN_CACHE = {}      # (B, H, W, T, blend, device index, mode) -> (plan dict | None, ctypes plan | None)
+
+
+def _resident_plan_cached(B, H, W, T, blend, dev):
+    key = (B, H, W, T, blend, dev.index, _RESIDENT_MODE)
+    hit = _RES_PLAN_CACHE.get(key)
+    if hit is None:
+        n_cu = _resident_state(dev)["n_cu"]
+        rp = resident_plan(B, H, W, T, blend, n_cu) if _RESIDENT_MODE == "on" else resident_pays(B, H, W, T, blend, dev)
+        cp = None
+        if rp is not None:
+            cp = _lib.cspn_resident_plan()
+            for name, _ in _lib.cspn_resident_plan._fields_:
+                if name != "debug_stamps":
+                    setattr(cp, name, rp[name])
+        if len(_RES_PLAN_CACHE) > 1024:
+            _RES_PLAN_CACHE.clear()
+        hit = _RES_PLAN_CACHE[key] = (rp, cp)
+    return hit
+
+
 def resident_pays(B, H, W, T, blend, dev):
     """Policy of mode "auto": the resident launch needs enough tiles to occupy the chip (one workgroup per CU) and a
     halo overhead that the saved weight passes pay for."""
     rp = resident_plan(B, H, W, T, blend, _resident_state(dev)["n_cu"])
     if rp is None:
         return None
-    # measured on MI355X (tools/bench_resident.py, profiles/r02_resident_vs_multilaunch.txt): one resident launch beats
-    # the three-launch schedule by 10 % (config 2) to 35 % (B <= 3 shards); batches that need a second resident launch
-    # (more tiles than CUs) are a tie or slower, and those stay on the multi-launch schedule
-    if rp["launches"] > 1 or rp["region_over_tile"] > 3.6:
+    # measured on MI355X (tools/bench_resident.py -> profiles/r02_resident_vs_multilaunch.txt): the resident schedule beats
+    # the three-launch one by 20 % at config 2, 12-15 % when the batch needs two resident launches (KITTI B=8, NYU B=48)
+    # and 20-35 % on per-GPU shards (B <= 6); only extreme halo overheads are left to the multi-launch schedule
+    if rp["region_over_tile"] > 3.6 or rp["launches"] > 4:
         return None
     return rp
 
@@ -553,11 +574,7 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
     B, H, W = d0.shape
     if guidance.stride(1) >= (1 << 27) or H * W >= (1 << 27):
         return None                                        # the kernel addresses an image with 32-bit element offsets
-    blend = int(sparse is not None)
-    dev = guidance.device
-    if _RESIDENT_MODE == "on":
-        return resident_plan(B, H, W, T, blend, _resident_state(dev)["n_cu"])
-    return resident_pays(B, H, W, T, blend, dev)
+    return _resident_plan_cached(B, H, W, int(T), int(sparse is not None), guidance.device)[0]
 
 
 def check_resident_errors(dev=None):
@@ -586,6 +603,8 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
         rp.steps_per_phase = int(steps_per_phase)
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
+    else:
+        rp = _resident_plan_cached(B, H, W, int(T), int(blend), dev)[1]      # found once per shape: the C side skips its search
     log = _EVENT_LOG
     with _RES_LOCK:
         st = _resident_state(dev)

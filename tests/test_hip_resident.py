@@ -154,3 +154,37 @@ def test_resident_timeout_is_loud_not_a_hang(c_oracle):
             ref = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dev(d))
     assert torch.equal(out, ref[:, 0])
     F.check_resident_errors()
+
+
+def test_resident_halo_comes_from_adjacent_tiles_only(c_oracle):
+    """Regression (round 2): a last tile row / column cut short by the image edge must not shift its region further than
+    the previous tile's start — the halo would come from a tile two away, which the exchange does not wait for.
+    KITTI B=1 (11x20 tiles of 112x18, last row 10 pixels high) and a few ragged shapes, against the oracle."""
+    for (B, H, W) in ((1, 352, 1216), (2, 100, 148), (1, 75, 300), (3, 41, 52)):
+        for T in (24, 9):
+            g, d, s = c_oracle.synthetic_inputs(120 + H, B, H, W, 12, 200)
+            want = c_oracle.cspn3_forward(g, d, s, T)
+            out = both(g, d, s, T)[0].cpu().numpy()
+            assert rel_err(out, want) <= 1e-5, (B, H, W, T)
+
+
+def test_resident_does_not_depend_on_leftover_state(c_oracle):
+    """Regression (round 2): LDS and the exchange planes keep whatever the previous launch left there.  Poison both with a
+    NaN-producing call, then alternate between different inputs: every output must still equal the multi-launch result
+    (an uninitialised ring row of the second LDS buffer once leaked the previous kernel's values into edge tiles)."""
+    m = pkg.CSPN_new.AffinityPropagate(24, 3)
+    for (B, H, W) in ((24, 228, 304), (8, 352, 1216), (3, 100, 148)):
+        sets = []
+        for k in range(3):
+            g, d, s = c_oracle.synthetic_inputs(200 + k + B, B, H, W, 12, 300)
+            sets.append((dev(g), dev(d), dev(s) if k == 1 else None))
+        poison = (torch.zeros_like(sets[0][0]), torch.full_like(sets[0][1], float("nan")), None)   # 0/0 weights, NaN depth
+        with torch.no_grad():
+            with resident("off"):
+                refs = [m(*c) for c in sets]
+            with resident("on"):
+                for rep in range(4):
+                    m(*poison)
+                    for k in (2, 0, 1, 1, 2, 0):
+                        assert torch.equal(m(*sets[k]), refs[k]), (B, H, W, rep, k)
+    F.check_resident_errors()

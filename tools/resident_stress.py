@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Developer tool: hammer the resident launch and compare every output with the multi-launch result (bit-exact)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cspn_monodepth_amd as pkg
+from cspn_monodepth_amd import functional as F
+dev = "cuda:0"
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+torch.manual_seed(0)
+bad_total = 0
+for (B, H, W) in ((24, 228, 304), (3, 228, 304), (1, 352, 1216), (8, 352, 1216)):
+    sets = []
+    for k in range(3):                      # alternate inputs: stale exchange data of the previous call must show up
+        g = torch.randn(B, 12, H, W, device=dev)
+        d = torch.rand(B, 1, H, W, device=dev) * 10
+        sets.append((g, d))
+    m = pkg.CSPN_new.AffinityPropagate(24, 3)
+    with torch.no_grad():
+        F.set_resident("off"); refs = [m(g, d) for g, d in sets]
+        F.set_resident("on")
+        bad = 0
+        n = iters if B * H * W < 2e6 else iters // 4
+        outs = []
+        for it in range(n):
+            k = it % 3
+            outs.append((k, m(*sets[k])))
+            if len(outs) == 15:
+                for k2, o in outs:
+                    if not torch.equal(o, refs[k2]):
+                        bad += 1
+                        if bad <= 3:
+                            diff = (o != refs[k2]) | (torch.isnan(o) != torch.isnan(refs[k2]))
+                            idx = diff.nonzero()
+                            print("  mismatch at iter ~%d: %d px, first %s, last %s" % (it, idx.shape[0], idx[0].tolist(), idx[-1].tolist()))
+                outs = []
+    F.check_resident_errors()
+    print("B=%d %dx%d: %d / %d mismatching outputs" % (B, H, W, bad, n), flush=True)
+    bad_total += bad
+F.set_resident("auto")
+sys.exit(1 if bad_total else 0)
