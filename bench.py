@@ -112,6 +112,25 @@ def load_pmc_traffic(tag):
     return out
 
 
+def load_train_traffic(tag):
+    """Measured HBM bytes of one forward+backward of the module (tools/run_train_leg.py under rocprofv3 --pmc), from the
+    committed summary profiles/r*_pmc_traffic_<tag>bwd.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%sbwd.json" % tag)), reverse=True)
+    if not files:
+        return None
+    try:
+        j = json.load(open(files[0]))
+        ks = {k: v for k, v in j["per_kernel"]["fused"].items() if "hbm_bytes_corrected" in v}
+        iters = min(v["_dispatches_FETCH_SIZE"] for k, v in ks.items() if k.startswith("cspn_grad_tail"))
+        per = {k: [v["hbm_bytes_corrected"], v["_dispatches_FETCH_SIZE"] / iters] for k, v in ks.items()}
+        return {"bytes_per_step": sum(b * n for b, n in per.values()), "per_kernel": per,
+                "source": "profiles/%s%s" % (os.path.basename(files[0]), "; measured at commit %s" % j["commit"] if j.get("commit") else ""),
+                "stale": (j.get("source_digest") != pkg._lib._source_digest([])) if j.get("source_digest") else None}
+    except Exception:
+        return None
+
+
 def cpu_baseline(wl, budget_s=16.0):
     """The reference's CPU op mix (oracle/ref_plumbing_torch.py, a port validated bit-identical to the imported
     reference) on this box's host cores, on a bounded sample of the same workload: single frames and a
@@ -642,6 +661,16 @@ def main():
         dtt = (time.perf_counter() - t0t) / nt
         train = {"fwd_bwd_us": dtt * 1e6, "maps_per_s": B_local / dtt, "steps": nt,
                  "note": "CSPN module only (forward keeping T depth planes + reverse sweep + fused backward tail)"}
+        tb = load_train_traffic(args.workload + ("_sparse" if args.sparse else ""))
+        if tb is not None:           # HBM roofline of the training-shaped step on its MEASURED traffic (PMC passes, committed file)
+            train["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                 "hbm_traffic_bytes_per_step": tb["bytes_per_step"],
+                                 "achieved": tb["bytes_per_step"] / dtt / 1e9,
+                                 "frac": tb["bytes_per_step"] / dtt / 1e9 / HBM_PEAK_GBS,
+                                 "per_kernel_bytes_x_launches": tb["per_kernel"], "traffic_source": tb["source"],
+                                 "traffic_stale": tb["stale"],
+                                 "note": "achieved = measured HBM bytes of one forward+backward / its wall time (launch gaps and "
+                                         "autograd host time included)"}
         del gt, dt_, cot
 
     # ---- what a plain device copy achieves on this GPU (fraction of achievable, next to nominal)

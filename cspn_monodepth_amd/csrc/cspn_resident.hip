@@ -68,7 +68,11 @@ __device__ __forceinline__ float ld1_dev(const float* p) {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-template <int NQ, int NTHREADS, int BLEND, int SCORE>
+// CLEAN = 1: the host verified that every region of the launch lies inside the image (shifted regions, image at least one
+// region large, no row padding): the step body carries no zero-padding selects.  A launch-level property, so that each
+// instance holds ONE copy of the step body (+ the peeled final step) — two copies in one kernel cost the 256-VGPR
+// instances their spill-free hot loop.
+template <int NQ, int NTHREADS, int BLEND, int SCORE, int CLEAN>
 __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     constexpr int R = 1, NT = 8, WIN = 6;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -203,13 +207,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             }
         }
     }
-    // Wavefronts whose quads all lie inside the image (every wavefront, once the regions are shifted into an image that is
-    // at least one region large) run a step body without the zero-padding selects.
-    bool needs_pad = false;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i)
-        if (r0 + i < wr && (!((in_img >> i) & 1u) || nval < 4)) needs_pad = true;
-    const bool wave_clean = __builtin_amdgcn_ballot_w64(needs_pad) == 0ull;
     // park the depth region (its loads were requested before the guidance: only those are waited for here)
 #pragma unroll
     for (int u = 0; u <= NQ; ++u) {
@@ -357,9 +354,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         }
         // One propagation step on the LDS tile.  FINAL (the very last step of the forward) is peeled into its own copy so
         // that the target quads of the fused metrics are only live there, not across the hot loop.
-        auto step = [&](auto final_c, auto clean_c) __attribute__((always_inline)) {
+        auto step = [&](auto final_c) __attribute__((always_inline)) {
             constexpr bool FINAL = decltype(final_c)::value;
-            constexpr bool CLEAN = decltype(clean_c)::value;     // every quad of this wavefront lies inside the image
             if (active) {
                 float win[NQ + 2 * R][WIN];
                 auto row_ptr = [&](int rr) -> const float* {
@@ -431,13 +427,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         };
         stamp();                               // depth staged
         const int plain_steps = last_phase ? steps - 1 : steps;
-        if (!BLEND && wave_clean) {        // (the sparse variant is at the 256-VGPR limit: a second copy of the step body made it spill)
-            for (int s = 0; s < plain_steps; ++s) step(std::false_type{}, std::true_type{});
-            if (last_phase) step(std::true_type{}, std::true_type{});
-        } else {
-            for (int s = 0; s < plain_steps; ++s) step(std::false_type{}, std::false_type{});
-            if (last_phase) step(std::true_type{}, std::false_type{});
-        }
+        for (int s = 0; s < plain_steps; ++s) step(std::false_type{});
+        if (last_phase) step(std::true_type{});
         stamp();                               // steps of the phase done
         if (!last_phase) {
             // -- publish the interior quads (device scope), then the phase flag; wait for the 8 neighbouring tiles
@@ -546,6 +537,26 @@ int cu_count() {
     return prop.multiProcessorCount;
 }
 
+// Mirror of the kernel's region placement: does every region of every tile lie inside the (valid part of the) image?
+bool regions_inside_image(const ResGeom& g, int H, int W, int Wv) {
+    if (Wv != W) return false;
+    for (int tx = 0; tx < g.tiles_x; ++tx) {
+        const int x0 = tx * g.tw;
+        int rx0 = x0 - g.hxw; if (rx0 > W - 4 * g.wq) rx0 = W - 4 * g.wq;
+        int lo = x0 - g.tw; if (lo < 0) lo = 0;
+        if (rx0 < lo) rx0 = lo;
+        if (rx0 + 4 * g.wq > W) return false;
+    }
+    for (int ty = 0; ty < g.tiles_y; ++ty) {
+        const int y0 = ty * g.th;
+        int ry0 = y0 - g.hyw; if (ry0 > H - g.wr) ry0 = H - g.wr;
+        int lo = y0 - g.th; if (lo < 0) lo = 0;
+        if (ry0 < lo) ry0 = lo;
+        if (ry0 + g.wr > H) return false;
+    }
+    return true;
+}
+
 // Tiling of one image for the resident kernel: every workgroup owns a tw x th tile + (S-1) halo; a launch holds
 // imgs_per_launch whole images on at most `ncu` workgroups.  Cost model: launches x (quads per thread + latency floor).
 bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_user, ResGeom* best) {
@@ -577,8 +588,11 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
                 int ipl = ncu / tiles;
                 if (ipl > B) ipl = B;
                 const int launches = ceil_div(B, ipl);
-                // per launch: derive (~2 steps' worth per quad) + T steps, each ~ (nq + 1.5) units; + exchange latency
-                const double cost = launches * ((T + 2.0) * (nq + 1.5) + 6.0 * (phases - 1));
+                ResGeom cand{Se, tx, ty, tw, th, nq, wq, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, 0.0};
+                // per launch: derive (~2 steps' worth per quad) + T steps, each ~ (nq + 1.5) units (x 1.13 with the zero-padding
+                // selects of a launch whose regions stick out of the image); + exchange latency
+                const double step_units = (nq + 1.5) * (regions_inside_image(cand, H, W, W) ? 1.0 : 1.13);
+                const double cost = launches * ((T + 2.0) * step_units + 6.0 * (phases - 1));
                 if (!found || cost < best->cost) {
                     found = true;
                     *best = ResGeom{Se, tx, ty, tw, th, nq, wq, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, cost};
@@ -589,9 +603,9 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
     return found;
 }
 
-template <int NQ, int BLEND, int SCORE>
+template <int NQ, int BLEND, int SCORE, int CLEAN>
 int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, SCORE>;
+    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, SCORE, CLEAN>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -604,11 +618,16 @@ int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream
     return 1;
 }
 
-template <int NQ>
-int launch_resident_nq(const ResArgs& a, int grid, size_t lds, int blend, bool score, hipStream_t st) {
-    if (blend) return score ? launch_resident_inst<NQ, 1, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0>(a, grid, lds, st);
-    return score ? launch_resident_inst<NQ, 0, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0>(a, grid, lds, st);
+template <int NQ, int CLEAN>
+int launch_resident_c(const ResArgs& a, int grid, size_t lds, int blend, bool score, hipStream_t st) {
+    if (blend) return score ? launch_resident_inst<NQ, 1, 1, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0, CLEAN>(a, grid, lds, st);
+    return score ? launch_resident_inst<NQ, 0, 1, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0, CLEAN>(a, grid, lds, st);
 }
+template <int NQ>
+int launch_resident_nq(const ResArgs& a, int grid, size_t lds, int blend, bool score, bool clean, hipStream_t st) {
+    return clean ? launch_resident_c<NQ, 1>(a, grid, lds, blend, score, st) : launch_resident_c<NQ, 0>(a, grid, lds, blend, score, st);
+}
+
 
 }  // namespace
 
@@ -694,17 +713,18 @@ int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d
     a.wq = g.wq; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
     a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);   // x (sc1 load + s_sleep) ~ seconds
     a.dbg = rp.debug_stamps;
+    const bool clean = regions_inside_image(g, H, W, a.Wv);
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
         switch (g.nq) {
-            case 1: ok = launch_resident_nq<1>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
-            case 2: ok = launch_resident_nq<2>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
-            case 3: ok = launch_resident_nq<3>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
-            case 4: ok = launch_resident_nq<4>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
-            case 5: ok = launch_resident_nq<5>(a, grid, g.lds_bytes, blend, acc != nullptr, st); break;
+            case 1: ok = launch_resident_nq<1>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
+            case 2: ok = launch_resident_nq<2>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
+            case 3: ok = launch_resident_nq<3>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
+            case 4: ok = launch_resident_nq<4>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
+            case 5: ok = launch_resident_nq<5>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
             default: return fail("cspn3_forward_resident: no instance for %d quads per thread", g.nq);
         }
         if (!ok) return 0;
