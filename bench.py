@@ -75,9 +75,10 @@ def make_inputs(wl, B, device, seed, sparse):
     return g, d, s, target
 
 
-def load_pmc_traffic(tag):
+def load_pmc_traffic(tag, schedule="fused"):
     """HBM traffic per launch from the committed rocprofv3 --pmc summary of this workload (profiles/*_pmc_traffic_<tag>
-    .json, newest round first).  `stale` = the kernel sources changed since the file was measured."""
+    .json, newest round first).  `schedule`: "fused" = the passes of the default schedule (the weight-resident launch
+    where it applies), "multi" = the passes with CSPN_RESIDENT=off.  `stale` = the kernel sources changed since."""
     import glob
     out = {"source": None, "stale": None, "step_bytes_per_launch": None, "fused_bytes_per_forward": None,
            "fused_per_launch": None, "sq": None}
@@ -95,7 +96,8 @@ def load_pmc_traffic(tag):
     except Exception:
         out["stale"] = None
     pk = j.get("per_kernel", {})
-    fused = [(k, v) for k, v in pk.get("fused", {}).items() if k.startswith(("cspn_prop", "cspn3_resident")) and "hbm_bytes_corrected" in v]
+    sched = pk.get(schedule) or pk.get("fused", {})
+    fused = [(k, v) for k, v in sched.items() if k.startswith(("cspn_prop", "cspn3_resident")) and "hbm_bytes_corrected" in v]
     if fused:
         n_fwd = min(v["_dispatches_FETCH_SIZE"] for _, v in fused)       # every instance runs >= once per forward
         out["fused_per_launch"] = {k: v["hbm_bytes_corrected"] for k, v in fused}
@@ -510,7 +512,10 @@ def main():
     # measured HBM traffic (rocprofv3 --pmc passes, tools/pmc_session.sh -> tools/pmc_traffic.py): NOT collected by this
     # run — counters need their own rocprofv3 passes — so the figures are quoted from the committed summary together with
     # the source digest of the kernels they were measured on (`traffic_stale` = the kernels changed since).
-    pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""))
+    pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""), "fused" if res_plan is not None else "multi")
+    if args.batch > 0 or world > 1:                     # the committed passes were measured on the workload's own batch on one GPU
+        pmc = dict(pmc, step_bytes_per_launch=None, fused_bytes_per_forward=None, fused_per_launch=None, sq=None,
+                   source=None if pmc["source"] is None else pmc["source"] + " [not applicable: batch overridden / sharded]")
 
     # ---- the north-star schedule: ONE launch per propagation step (S = 1), measured in the same process.  This is the
     # HBM-bound kernel the contract's `roofline` block describes: its algorithmic bytes ARE its HBM traffic.
@@ -661,7 +666,7 @@ def main():
         dtt = (time.perf_counter() - t0t) / nt
         train = {"fwd_bwd_us": dtt * 1e6, "maps_per_s": B_local / dtt, "steps": nt,
                  "note": "CSPN module only (forward keeping T depth planes + reverse sweep + fused backward tail)"}
-        tb = load_train_traffic(args.workload + ("_sparse" if args.sparse else ""))
+        tb = None if args.batch > 0 else load_train_traffic(args.workload + ("_sparse" if args.sparse else ""))
         if tb is not None:           # HBM roofline of the training-shaped step on its MEASURED traffic (PMC passes, committed file)
             train["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                  "hbm_traffic_bytes_per_step": tb["bytes_per_step"],

@@ -567,6 +567,8 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
     """Can this no-grad 3x3 forward take the weight-resident launch?  (fp32, whole 16-byte quads, no explicit plan.)"""
     if _RESIDENT_MODE == "off" or plan is not None or _DEFAULT_PLANS.get(3) is not None or T < 1:
         return None
+    if torch.cuda.is_current_stream_capturing():
+        return None        # a HIP-graph replay would re-use the captured flag sequence number: the neighbour waits would not wait
     if guidance.dtype != torch.float32 or d0.dtype != torch.float32 or not from_guidance_supported(guidance, d0, sparse, None):
         return None
     if target is not None and (target.dtype != torch.float32 or target.data_ptr() % 16):

@@ -188,3 +188,20 @@ def test_resident_does_not_depend_on_leftover_state(c_oracle):
                     for k in (2, 0, 1, 1, 2, 0):
                         assert torch.equal(m(*sets[k]), refs[k]), (B, H, W, rep, k)
     F.check_resident_errors()
+
+
+def test_resident_is_not_captured_into_hip_graphs(c_oracle):
+    """A captured resident launch would replay with a stale flag sequence number (its neighbour waits would not wait):
+    under stream capture the module must fall back to the multi-launch schedule, and the replay must stay correct."""
+    B, H, W, T = 3, 100, 148, 24
+    g, d, _ = c_oracle.synthetic_inputs(130, B, H, W, 12, None)
+    gt, dt = dev(g), dev(d)
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad(), resident("on"):
+        ref = m(gt, dt)
+        graphed = pkg.graphs.GraphedForward(lambda: m(gt, dt))
+        for _ in range(3):
+            out = graphed(copy_inputs=False)
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    F.check_resident_errors()
