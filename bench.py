@@ -509,7 +509,7 @@ def main():
     alg_bytes_per_launch = bytes_px_step * B_local * wl["H"] * wl["W"] * (T / max(1, -(-T // S)))
     avg_launch_s = (prop_ms / 1e3) / max(n_launch, 1)
     achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
-    # measured HBM traffic (rocprofv3 --pmc passes, tools/pmc_session.sh -> tools/pmc_traffic.py): NOT collected by this
+    # measured HBM traffic (rocprofv3 --pmc passes, tools/r02_profile_session.sh -> tools/pmc_traffic.py): NOT collected by this
     # run — counters need their own rocprofv3 passes — so the figures are quoted from the committed summary together with
     # the source digest of the kernels they were measured on (`traffic_stale` = the kernels changed since).
     pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""), "fused" if res_plan is not None else "multi")

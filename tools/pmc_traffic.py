@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes written by tools/pmc_session.sh into per-kernel averages and the
+"""Summarise rocprofv3 --pmc passes written by tools/r02_profile_session.sh into per-kernel averages and the
 HBM-traffic figure bench.py reports as roofline.traffic (profiles/traffic_<workload>.json).
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B, so wide
