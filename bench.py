@@ -513,6 +513,8 @@ def main():
     # run — counters need their own rocprofv3 passes — so the figures are quoted from the committed summary together with
     # the source digest of the kernels they were measured on (`traffic_stale` = the kernels changed since).
     pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""), "fused" if res_plan is not None else "multi")
+    if res_plan is not None and pmc["fused_per_launch"]:    # one resident instance, `launches` dispatches of it per forward
+        pmc["fused_bytes_per_forward"] = sum(pmc["fused_per_launch"].values()) * res_plan["launches"]
     if args.batch > 0 or world > 1:                     # the committed passes were measured on the workload's own batch on one GPU
         pmc = dict(pmc, step_bytes_per_launch=None, fused_bytes_per_forward=None, fused_per_launch=None, sq=None,
                    source=None if pmc["source"] is None else pmc["source"] + " [not applicable: batch overridden / sharded]")
