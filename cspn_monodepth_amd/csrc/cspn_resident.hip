@@ -40,7 +40,10 @@ struct ResArgs {
     unsigned* status;        // [0] abort word of the running launch chain, [1] sticky error word (workspace)
     unsigned* host_err;      // optional host-mapped word that receives the error as well
     unsigned seq;            // flag base of this call: a tile that finished phase p publishes seq + p + 1
-    const float* target;     // SCORE: [B,H,W]
+    float* hist;             // MODE 2: [T][B,H,W] receives the state after every step (d_1 .. d_T), `out` is unused
+    float* w_out;            // MODE 2: [B,8,H,W] receives the normalised weights (the backward streams them)
+    float* s_out;            // MODE 2: [B,H,W] receives the normaliser S (the backward's quotient rule needs it)
+    const float* target;     // MODE 1: [B,H,W]
     double* macc;
     int nslots;
     int B, H, W, Wv, T, S;
@@ -72,9 +75,16 @@ __device__ __forceinline__ float ld1_dev(const float* p) {
 // region large, no row padding): the step body carries no zero-padding selects.  A launch-level property, so that each
 // instance holds ONE copy of the step body (+ the peeled final step) — two copies in one kernel cost the 256-VGPR
 // instances their spill-free hot loop.
-template <int NQ, int NTHREADS, int BLEND, int SCORE, int CLEAN>
+// MODE 0: inference; 1: inference + fused depth metrics; 2: training forward — every step's state goes to its history
+// plane and the weights + S are published once (what cspn3_propagate_from_guidance hands the backward).
+template <int NQ, int NTHREADS, int BLEND, int MODE, int CLEAN>
 __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     constexpr int R = 1, NT = 8, WIN = 6;
+    // MODE 3: the backward's reverse sweep  G_t = stencil^T((1-m) G_{t+1})  as the same recurrence on the TRANSPOSED taps:
+    // tap j = w_{7-j}[p + off_j], gathered from the forward tap volume [B,8,H,W] (a.g) exactly like channel 7-j of the
+    // guidance is gathered for the forward — minus |.| and the normalisation.  BLEND then means PREMASK: the state that
+    // travels (LDS, exchange planes) is (1-m) G, the history planes receive G itself.  d0 is G_T = dL/dout.
+    constexpr bool SCORE = MODE == 1, TRANS = MODE == 3, HIST = MODE == 2 || TRANS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int wg_bad;
 
@@ -138,6 +148,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         const bool in = valid && (y >= 0 && y < H && x >= 0 && x < a.Wv);
         if (in) st0_in |= 1u << u;
         st0[u] = ld4(din0 + (in ? (unsigned)(y * W + x) : 0u));
+        if (TRANS && BLEND) {                          // PREMASK: the sweep starts from (1-m) G_T
+            const float4 sp = ld4(spg + (in ? (unsigned)(y * W + x) : 0u));
+            st0[u].x *= 1.f - sgnf(sp.x); st0[u].y *= 1.f - sgnf(sp.y); st0[u].z *= 1.f - sgnf(sp.z); st0[u].w *= 1.f - sgnf(sp.w);
+        }
         at0[u] = valid ? row * ls + 4 + 4 * qx : -1;
     }
     float ring0 = 0.f;
@@ -149,6 +163,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         const int y = yd0 + row, x = xd0 + lc;
         ring0_in = (y >= 0 && y < H && x >= 0 && x < a.Wv);
         ring0 = ld1(din0 + (ring0_in ? (unsigned)(y * W + x) : 0u));
+        if (TRANS && BLEND) ring0 *= 1.f - sgnf(ld1(spg + (ring0_in ? (unsigned)(y * W + x) : 0u)));
         ring0_at = row * ls + lc;
     }
 
@@ -233,22 +248,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 const int t = j == 0 ? 0 : (j == 3 ? 1 : 2);
                 const float nb = dpp_from_prev_lane(q3);
                 const float lf = fix_left ? (((edge_ok >> (i * 6 + t)) & 1u) ? edge[i][t] : 0.f) : nb;
-                wreg[i][j][0] = fabsf(lf); wreg[i][j][1] = fabsf(q0); wreg[i][j][2] = fabsf(q1); wreg[i][j][3] = fabsf(q2);
+                wreg[i][j][0] = TRANS ? lf : fabsf(lf); wreg[i][j][1] = TRANS ? q0 : fabsf(q0); wreg[i][j][2] = TRANS ? q1 : fabsf(q1); wreg[i][j][3] = TRANS ? q2 : fabsf(q2);
             } else if (dx > 0) {
                 const int t = j == 2 ? 3 : (j == 4 ? 4 : 5);
                 const float nb = dpp_from_next_lane(q0);
                 const float rt = fix_right ? (((edge_ok >> (i * 6 + t)) & 1u) ? edge[i][t] : 0.f) : nb;
-                wreg[i][j][0] = fabsf(q1); wreg[i][j][1] = fabsf(q2); wreg[i][j][2] = fabsf(q3); wreg[i][j][3] = fabsf(rt);
+                wreg[i][j][0] = TRANS ? q1 : fabsf(q1); wreg[i][j][1] = TRANS ? q2 : fabsf(q2); wreg[i][j][2] = TRANS ? q3 : fabsf(q3); wreg[i][j][3] = TRANS ? rt : fabsf(rt);
             } else {
-                wreg[i][j][0] = fabsf(q0); wreg[i][j][1] = fabsf(q1); wreg[i][j][2] = fabsf(q2); wreg[i][j][3] = fabsf(q3);
+                wreg[i][j][0] = TRANS ? q0 : fabsf(q0); wreg[i][j][1] = TRANS ? q1 : fabsf(q1); wreg[i][j][2] = TRANS ? q2 : fabsf(q2); wreg[i][j][3] = TRANS ? q3 : fabsf(q3);
             }
         }
         // S in the reference's channel order k = 0..7 (tap 7..0), one shared refined reciprocal; 0 for padding quads
+        float Sq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (TRANS) {                                   // the taps are final: only quads outside the image are zeroed
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? wreg[i][j][e] : 0.f;
+        } else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float S = wreg[i][7][e];
 #pragma unroll
             for (int k = 1; k < 8; ++k) S += wreg[i][7 - k][e];
+            Sq[e] = S;
             float av[8], qv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) av[j] = wreg[i][j][e];
@@ -256,18 +279,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? qv[j] : 0.f;
         }
+        if (MODE == 2 && ((interior >> i) & 1u)) {   // publish before the blend is folded in: the backward wants w and S themselves
+            store_taps_quad<NT>(a.w_out + (size_t)b * NT * HW, off, HW, wreg[i]);
+            st4(a.s_out + (size_t)b * HW + off, make_float4(Sq[0], Sq[1], Sq[2], Sq[3]));
+        }
         if (BLEND && r < wr) {
             // (1-m) u + m d0  ==  sum_j ((1-m) w_j) d_j + m d0 with 1-m in {0,1,2}: exact, so bit-identical (CSPN_new.py:90)
             const float4 mraw = ld4(spg + off);                   // off = 0 for quads outside the image
             const float4 m = make_float4(ok ? sgnf(mraw.x) : 0.f, ok ? sgnf(mraw.y) : 0.f, ok ? sgnf(mraw.z) : 0.f, ok ? sgnf(mraw.w) : 0.f);
             const float omq[4] = {1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w};
+            if (TRANS) {                               // PREMASK: the private plane holds 1-m, applied to every step's result
+                *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) = make_float4(omq[0], omq[1], omq[2], omq[3]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wreg[i][j][e] *= omq[e];
-            const float4 v = ld4(din0 + off);
-            *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) =
-                make_float4(ok ? m.x * v.x : 0.f, ok ? m.y * v.y : 0.f, ok ? m.z * v.z : 0.f, ok ? m.w * v.w : 0.f);
+                    for (int e = 0; e < 4; ++e) wreg[i][j][e] *= omq[e];
+                const float4 v = ld4(din0 + off);
+                *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) =
+                    make_float4(ok ? m.x * v.x : 0.f, ok ? m.y * v.y : 0.f, ok ? m.z * v.z : 0.f, ok ? m.w * v.w : 0.f);
+            }
         }
     }
 
@@ -275,7 +306,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // ---- 2. phases of S steps; between phases the tile borders travel through the exchange planes ---------------------
     const bool active = (r0 < wr);
     const int cb = 4 + 4 * sx;
-    float* __restrict__ dout = a.out + (size_t)b * HW;
+    float* __restrict__ dout = HIST ? nullptr : a.out + (size_t)b * HW;
+    float* hist_step = HIST ? a.hist + (size_t)b * HW : nullptr;      // plane of the step being computed (uniform)
     const int n_phase = (a.T + a.S - 1) / a.S;
     const int tile_global = b * tiles_per_img + trem;
     float own[NQ][4];
@@ -402,24 +434,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) u[e] = fmaf(wreg[i][j][e], win[i + dy + 1][e + dx + 1], u[e]);
                             }
+                        float keep[4];                 // the state carried to the next step
                         if (BLEND) {
                             const float4 m4 = *reinterpret_cast<const float4*>(md_lds + ((r0 + i) * wq + sx) * 4);
-                            u[0] += m4.x; u[1] += m4.y; u[2] += m4.z; u[3] += m4.w;
+                            if (TRANS) {
+                                keep[0] = m4.x * u[0]; keep[1] = m4.y * u[1]; keep[2] = m4.z * u[2]; keep[3] = m4.w * u[3];
+                            } else {
+                                u[0] += m4.x; u[1] += m4.y; u[2] += m4.z; u[3] += m4.w;
+                            }
+                        }
+                        if (!(TRANS && BLEND)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) keep[e] = u[e];
                         }
                         if (!CLEAN) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (!((in_img >> i) & 1u) || e >= nval) u[e] = 0.f;   // zero padding stays exactly zero
+                                if (!((in_img >> i) & 1u) || e >= nval) { u[e] = 0.f; keep[e] = 0.f; }   // zero padding stays exactly zero
                         }
                         if (!FINAL)
-                            *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) = make_float4(u[0], u[1], u[2], u[3]);
+                            *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) = make_float4(keep[0], keep[1], keep[2], keep[3]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) own[i][e] = u[e];
-                        if (FINAL && ((interior >> i) & 1u))
+                        for (int e = 0; e < 4; ++e) own[i][e] = keep[e];
+                        if (HIST) {
+                            if ((interior >> i) & 1u) st4(hist_step + (unsigned)((yq0 + i) * W + xq), make_float4(u[0], u[1], u[2], u[3]));
+                        } else if (FINAL && ((interior >> i) & 1u)) {
                             st4(dout + (size_t)(yq0 + i) * W + xq, make_float4(u[0], u[1], u[2], u[3]));
+                        }
                     }
                 }
             }
+            if (HIST) hist_step += plane;
             if (!FINAL) {
                 __syncthreads();
                 float* t = cur; cur = nxt; nxt = t;
@@ -603,9 +648,9 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
     return found;
 }
 
-template <int NQ, int BLEND, int SCORE, int CLEAN>
+template <int NQ, int BLEND, int MODE, int CLEAN>
 int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, SCORE, CLEAN>;
+    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, MODE, CLEAN>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -619,17 +664,29 @@ int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream
 }
 
 template <int NQ, int CLEAN>
-int launch_resident_c(const ResArgs& a, int grid, size_t lds, int blend, bool score, hipStream_t st) {
-    if (blend) return score ? launch_resident_inst<NQ, 1, 1, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0, CLEAN>(a, grid, lds, st);
-    return score ? launch_resident_inst<NQ, 0, 1, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0, CLEAN>(a, grid, lds, st);
+int launch_resident_c(const ResArgs& a, int grid, size_t lds, int blend, int mode, hipStream_t st) {
+    if (mode == 3) return blend ? launch_resident_inst<NQ, 1, 3, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 3, CLEAN>(a, grid, lds, st);
+    if (blend) {
+        if (mode == 2) return launch_resident_inst<NQ, 1, 2, CLEAN>(a, grid, lds, st);
+        return mode ? launch_resident_inst<NQ, 1, 1, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0, CLEAN>(a, grid, lds, st);
+    }
+    if (mode == 2) return launch_resident_inst<NQ, 0, 2, CLEAN>(a, grid, lds, st);
+    return mode ? launch_resident_inst<NQ, 0, 1, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0, CLEAN>(a, grid, lds, st);
 }
 template <int NQ>
-int launch_resident_nq(const ResArgs& a, int grid, size_t lds, int blend, bool score, bool clean, hipStream_t st) {
-    return clean ? launch_resident_c<NQ, 1>(a, grid, lds, blend, score, st) : launch_resident_c<NQ, 0>(a, grid, lds, blend, score, st);
+int launch_resident_nq(const ResArgs& a, int grid, size_t lds, int blend, int mode, bool clean, hipStream_t st) {
+    return clean ? launch_resident_c<NQ, 1>(a, grid, lds, blend, mode, st) : launch_resident_c<NQ, 0>(a, grid, lds, blend, mode, st);
 }
 
 
 }  // namespace
+
+namespace {
+int resident_launch(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out, void* history,
+                    void* w8_out, float* s_out, void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid,
+                    int T, int blend, const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
+                    cspn_stream_t stream, bool transposed);
+}
 
 extern "C" {
 
@@ -655,11 +712,39 @@ size_t cspn3_resident_workspace_bytes(int B, int H, int W) {
 }
 
 int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out,
+                           void* history, void* w8_out, float* s_out,
                            void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid, int T, int blend,
                            const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
                            cspn_stream_t stream) {
-    if (!guidance || !d0 || !out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1)
+    return resident_launch(guidance, bs, cs, d0, sparse, out, history, w8_out, s_out, work, seq, host_err, B, H, W, W_valid, T,
+                           blend, target, acc, nslots, plan, stream, /*transposed=*/false);
+}
+
+int cspn3_transposed_resident(const void* w8, const float* g_T, const float* sparse_f32, float* history, void* work,
+                              unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid, int T, int premask,
+                              const cspn_resident_plan* plan, cspn_stream_t stream) {
+    if (!w8 || !g_T || !history) return fail("cspn3_transposed_resident: bad arguments");
+    if (premask && !sparse_f32) return fail("cspn3_transposed_resident: premask needs sparse");
+    return resident_launch(w8, (long)8 * H * W, (long)H * W, g_T, premask ? sparse_f32 : nullptr, nullptr, history, nullptr, nullptr,
+                           work, seq, host_err, B, H, W, W_valid, T, premask ? 1 : 0, nullptr, nullptr, 0, plan, stream,
+                           /*transposed=*/true);
+}
+
+}  // extern "C"
+
+namespace {
+
+int resident_launch(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out,
+                    void* history, void* w8_out, float* s_out,
+                    void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid, int T, int blend,
+                    const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
+                    cspn_stream_t stream, bool transposed) {
+    if (!guidance || !d0 || !work || B <= 0 || H <= 0 || W <= 0 || T < 1 || (!out && !history))
         return fail("cspn3_forward_resident: bad arguments");
+    if (!transposed && history && (!w8_out || !s_out || target || acc || !aligned16(history) || !aligned16(w8_out) || !aligned16(s_out)))
+        return fail("cspn3_forward_resident: the training form (history) needs w8_out and s_out, 16-byte aligned, and no scoring");
+    if (!history && (w8_out || s_out)) return fail("cspn3_forward_resident: w8_out / s_out are outputs of the training form (history)");
+    if (transposed && !aligned16(history)) return fail("cspn3_transposed_resident: history must be 16-byte aligned");
     if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn3_forward_resident: blend %d", blend);
     if (blend && !sparse) return fail("cspn3_forward_resident: blend needs sparse");
     if ((target || acc) && (!target || !acc || nslots < 1 || !aligned16(target)))
@@ -667,7 +752,7 @@ int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d
     if ((W & 3) || (cs & 3) || (bs & 3)) return fail("cspn3_forward_resident: W and the guidance strides must be multiples of 4");
     if (cs < 0 || bs < 0 || cs >= (1L << 27) || (long)H * W >= (1L << 27))
         return fail("cspn3_forward_resident: images of >= 2^27 pixels / channel strides >= 2^27 elements are not supported (32-bit offsets)");
-    if (!aligned16(guidance) || !aligned16(d0) || !aligned16(out) || !aligned16(work) || (sparse && !aligned16(sparse)))
+    if (!aligned16(guidance) || !aligned16(d0) || (out && !aligned16(out)) || !aligned16(work) || (sparse && !aligned16(sparse)))
         return fail("cspn3_forward_resident: tensors must be 16-byte aligned");
     if (W_valid < 0 || W_valid > W) return fail("cspn3_forward_resident: W_valid=%d outside (0, W=%d]", W_valid, W);
     if (seq == 0 || seq > 0x7fffff00u) return fail("cspn3_forward_resident: seq must be in [1, 2^31 - 256]");
@@ -706,6 +791,8 @@ int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d
     if ((size_t)B * g.tiles_x * g.tiles_y > (size_t)B * (((size_t)H * W) / 16 + 1))
         return fail("cspn3_forward_resident: workspace too small for %d tiles", B * g.tiles_x * g.tiles_y);
     a.host_err = host_err;
+    a.hist = static_cast<float*>(history); a.w_out = static_cast<float*>(w8_out); a.s_out = s_out;
+    const int mode = transposed ? 3 : (history ? 2 : (acc ? 1 : 0));
     a.seq = seq;
     a.target = static_cast<const float*>(target); a.macc = acc; a.nslots = nslots;
     a.B = B; a.H = H; a.W = W; a.Wv = (W_valid > 0 && W_valid < W) ? W_valid : W; a.T = T; a.S = g.S;
@@ -720,11 +807,11 @@ int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
         switch (g.nq) {
-            case 1: ok = launch_resident_nq<1>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
-            case 2: ok = launch_resident_nq<2>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
-            case 3: ok = launch_resident_nq<3>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
-            case 4: ok = launch_resident_nq<4>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
-            case 5: ok = launch_resident_nq<5>(a, grid, g.lds_bytes, blend, acc != nullptr, clean, st); break;
+            case 1: ok = launch_resident_nq<1>(a, grid, g.lds_bytes, blend, mode, clean, st); break;
+            case 2: ok = launch_resident_nq<2>(a, grid, g.lds_bytes, blend, mode, clean, st); break;
+            case 3: ok = launch_resident_nq<3>(a, grid, g.lds_bytes, blend, mode, clean, st); break;
+            case 4: ok = launch_resident_nq<4>(a, grid, g.lds_bytes, blend, mode, clean, st); break;
+            case 5: ok = launch_resident_nq<5>(a, grid, g.lds_bytes, blend, mode, clean, st); break;
             default: return fail("cspn3_forward_resident: no instance for %d quads per thread", g.nq);
         }
         if (!ok) return 0;
@@ -732,4 +819,4 @@ int cspn3_forward_resident(const void* guidance, long bs, long cs, const void* d
     return 1;
 }
 
-}  // extern "C"
+}  // namespace

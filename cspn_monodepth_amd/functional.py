@@ -524,6 +524,7 @@ def _resident_state(dev):
     if st is None:
         host_err = torch.zeros(4, dtype=torch.int32).pin_memory()
         st = _RES[dev.index] = dict(seq=_RES_SEQ_STEP, work={}, host_err=host_err, host_err_np=host_err.numpy(),
+                                    host_err_ptr=ctypes.c_void_p(host_err.data_ptr()),
                                     last_stream=None, n_cu=torch.cuda.get_device_properties(dev).multi_processor_count)
     return st
 
@@ -592,25 +593,16 @@ def check_resident_errors(dev=None):
                                "CSPN_RESIDENT=off when the device is shared." % idx)
 
 
-def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None):
-    """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it."""
-    dev = _require_device(guidance, d0, sparse)
-    B, C, H, W = guidance.shape
+def _resident_launch(dev, B, H, W, T, launch):
+    """The host protocol of every resident launch on `dev`: one at a time per device (lock; a launch from another stream
+    first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence number,
+    the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call."""
     L = _lib.lib()
-    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    tg, acc = score if score is not None else (None, None)
-    rp = None
-    if steps_per_phase or spin_limit or debug_stamps is not None:
-        rp = _lib.cspn_resident_plan()
-        rp.steps_per_phase = int(steps_per_phase)
-        rp.spin_limit = int(spin_limit)
-        rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
-    else:
-        rp = _resident_plan_cached(B, H, W, int(T), int(blend), dev)[1]      # found once per shape: the C side skips its search
     log = _EVENT_LOG
     with _RES_LOCK:
         st = _resident_state(dev)
-        check_resident_errors(dev)
+        if st["host_err_np"][0] != 0:
+            check_resident_errors(dev)                  # raises
         key = (B, H, W)
         work = st["work"].get(key)
         if work is None:
@@ -632,14 +624,66 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
-            ok = L.cspn3_forward_resident(_p(guidance), guidance.stride(0), guidance.stride(1), _p(d0), _p(sparse), _p(out),
-                                          _p(work), seq, ctypes.c_void_p(st["host_err"].data_ptr()), B, H, W, int(valid_w),
-                                          int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
-                                          None if rp is None else ctypes.byref(rp), _stream(dev))
+            ok = launch(work, seq, st["host_err_ptr"], ctypes.c_void_p(cur.cuda_stream))
             if log is not None:
                 ev1.record(cur)
-                log.append((ev0, ev1, 1, int(T)))
+                log.append((ev0, ev1, 1, T))
+    return ok
+
+
+def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
+    """Reverse sweep of the backward as one weight-resident launch per chunk: ghist [T,B,H,W] (G_{T-1} .. G_0)."""
+    dev = _require_device(w8, g_T, sparse_f32)
+    B, H, W = g_T.shape
+    L = _lib.lib()
+    ghist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
+    rp = _resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1]
+
+    def launch(work, seq, host_err_ptr, stream_ptr):
+        return L.cspn3_transposed_resident(_p(w8), _p(g_T), _p(sparse_f32), _p(ghist), _p(work), seq, host_err_ptr, B, H, W,
+                                           int(valid_w), int(T), int(sparse_f32 is not None),
+                                           None if rp is None else ctypes.byref(rp), stream_ptr)
+
+    ok = _resident_launch(dev, B, H, W, int(T), launch)
+    _lib.check(ok, "cspn3_transposed_resident")
+    return ghist
+
+
+def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None,
+                     keep_history=False):
+    """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it.
+
+    keep_history=True is the training forward: returns (d_T [view of history[T-1]], history [T,B,H,W], w8 [B,8,H,W],
+    S [B,H,W]) — the launch writes every step's state to its history plane and publishes the weights and S once."""
+    dev = _require_device(guidance, d0, sparse)
+    B, C, H, W = guidance.shape
+    L = _lib.lib()
+    hist = w8 = S_out = out = None
+    if keep_history:
+        hist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
+        w8 = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
+        S_out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    tg, acc = score if score is not None else (None, None)
+    rp = None
+    if steps_per_phase or spin_limit or debug_stamps is not None:
+        rp = _lib.cspn_resident_plan()
+        rp.steps_per_phase = int(steps_per_phase)
+        rp.spin_limit = int(spin_limit)
+        rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
+    else:
+        rp = _resident_plan_cached(B, H, W, int(T), int(blend), dev)[1]      # found once per shape: the C side skips its search
+    def launch(work, seq, host_err_ptr, stream_ptr):
+        return L.cspn3_forward_resident(_p(guidance), guidance.stride(0), guidance.stride(1), _p(d0), _p(sparse), _p(out),
+                                        _p(hist), _p(w8), _p(S_out), _p(work), seq, host_err_ptr, B, H, W, int(valid_w),
+                                        int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
+                                        None if rp is None else ctypes.byref(rp), stream_ptr)
+
+    ok = _resident_launch(dev, B, H, W, int(T), launch)
     _lib.check(ok, "cspn3_forward_resident")
+    if keep_history:
+        return hist[int(T) - 1], hist, w8, S_out
     return out
 
 
@@ -664,9 +708,15 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
         g_T = g_T.clone()
     ghist = None
     if T > 0:
-        ghist = torch.empty((T, B, H, W), dtype=torch.float32, device=dev)
         sp32 = None if sparse is None else sparse.float()
         L = _lib.lib()
+        if (K == 3 and w.dtype == torch.float32 and w.dim() == 4 and W % 4 == 0 and w.data_ptr() % 16 == 0 and g_T.data_ptr() % 16 == 0
+                and (sp32 is None or sp32.data_ptr() % 16 == 0) and _RESIDENT_MODE != "off" and plan is None
+                and _DEFAULT_PLANS.get(3) is None and H * W < (1 << 27) and not torch.cuda.is_current_stream_capturing()
+                and _resident_plan_cached(B, H, W, int(T), int(sp32 is not None), dev)[0] is not None):
+            # weight-resident reverse sweep: the transposed taps are gathered once and stay in registers for all T steps
+            return g_T, transposed_resident(w, g_T, sp32, T, valid_w)
+        ghist = torch.empty((T, B, H, W), dtype=torch.float32, device=dev)
         p = None
         if W % 4 == 0 and w.data_ptr() % 16 == 0 and (sp32 is None or sp32.data_ptr() % 16 == 0):
             p = resolve_plan(K, B, H, W, T, True, plan)
@@ -730,7 +780,11 @@ class CSPN3Function(torch.autograd.Function):
             # inference: no separate prepare pass (the first launch derives and publishes the weights)
             out, _ = propagate_from_guidance(guidance, d0, sp, prop_time, blend, plan=plan, valid_w=valid_w)
             return out.unsqueeze(1)
-        if need_grad and _FROM_GUIDANCE and prop_time > 0 and from_guidance_supported(guidance, d0, sp, plan):
+        if need_grad and prop_time > 0 and resident_supported(guidance, d0, sp, prop_time, plan) is not None:
+            # training, weight-resident: one launch writes the T depth planes and publishes the weights + S for the backward
+            g = guidance
+            out, hist, w8, S = forward_resident(g, d0, sp, prop_time, blend, valid_w=valid_w, keep_history=True)
+        elif need_grad and _FROM_GUIDANCE and prop_time > 0 and from_guidance_supported(guidance, d0, sp, plan):
             # training: the first launch derives the weights, publishes them and S for the backward, and the loop keeps
             # the T depth planes — one pass over the guidance instead of a prepare pass + a re-read of the volume
             g = guidance

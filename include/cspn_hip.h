@@ -250,10 +250,23 @@ typedef struct cspn_resident_plan {
 /* n_cu <= 0: ask the current device.  Returns 0 (with a message) when no tiling fits. */
 int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
 size_t cspn3_resident_workspace_bytes(int B, int H, int W);
+/* Training form: history != NULL ([T,B,H,W] f32, receives d_1..d_T; `out` may be NULL) together with w8_out ([B,8,H,W])
+ * and s_out ([B,H,W]): the launch also publishes the normalised weights and the normaliser S once — exactly what
+ * cspn3_propagate_from_guidance hands the backward (cspn_propagate_transposed, cspn3_backward_tail).  No scoring then. */
 int cspn3_forward_resident(const void* guidance, long g_batch_stride, long g_chan_stride, const void* d0,
-                           const void* sparse_or_null, void* out, void* work, unsigned seq, unsigned* host_err_or_null,
+                           const void* sparse_or_null, void* out, void* history_or_null, void* w8_out_or_null,
+                           float* s_out_or_null, void* work, unsigned seq, unsigned* host_err_or_null,
                            int B, int H, int W, int W_valid, int T, int blend, const void* target_or_null,
                            double* acc_or_null, int nslots, const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
+
+/* The backward's reverse sweep G_t = stencil^T((1-m) G_{t+1}), t = T-1..0, as ONE weight-resident launch per chunk of
+ * images: the transposed taps are gathered once from the forward tap volume w8 [B,8,H,W] (f32) and stay in registers.
+ * history [T,B,H,W] receives G_{T-1} .. G_0 in that order (as cspn_propagate_transposed); premask != 0 applies (1-m),
+ * m = sign(sparse_f32).  Workspace / seq / host_err / plan exactly as cspn3_forward_resident (the two may share one
+ * workspace).  Bit-identical to cspn_propagate_transposed. */
+int cspn3_transposed_resident(const void* w8, const float* g_T, const float* sparse_f32_or_null, float* history, void* work,
+                              unsigned seq, unsigned* host_err_or_null, int B, int H, int W, int W_valid, int T, int premask,
+                              const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
 
 /* A/B + test switch (process-wide): on != 0 makes every cspn_pac_* entry skip its LDS-tiled kernels and run the generic
  * one-quad-per-thread kernels; the previous setting is stored to *previous_or_null.  The initial value is read once from

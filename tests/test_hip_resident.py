@@ -205,3 +205,51 @@ def test_resident_is_not_captured_into_hip_graphs(c_oracle):
         torch.cuda.synchronize()
     assert torch.equal(out, ref)
     F.check_resident_errors()
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (2, 37, 8, 7), (5, 60, 64, 9)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_resident_training_forward_publishes_what_the_backward_needs(B, H, W, T, sparse, c_oracle):
+    """The training form of the resident launch (history planes, weights and S published once) against the multi-launch
+    training forward: every history plane, the tap volume and S bit for bit; gradients through the module against the
+    fp64 oracle."""
+    g, d, s = c_oracle.synthetic_inputs(150 + B + T, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    gt, dt = dev(g), dev(d)[:, 0].contiguous()
+    st = dev(s)[:, 0].contiguous() if sparse else None
+    blend = F.BLEND_SPARSE if sparse else F.BLEND_NONE
+    with torch.no_grad():
+        _, hist0, w0, S0 = F.propagate_from_guidance(gt, dt, st, T, blend, keep_history=True, return_weights=True)
+        out1, hist1, w1, S1 = F.forward_resident(gt, dt, st, T, int(sparse), keep_history=True)
+    assert torch.equal(hist1, hist0) and torch.equal(w1, w0) and torch.equal(S1, S0) and torch.equal(out1, hist0[T - 1])
+    # through autograd (mode "on": the training forward takes the resident launch)
+    cot = c_oracle.hash_normal(151, 9, (B, 1, H, W))
+    wg, wd = c_oracle.cspn3_backward(g, d, s, cot, T, np.float64)
+    ga, da = dev(g).requires_grad_(True), dev(d).requires_grad_(True)
+    with resident("on"):
+        assert F.resident_supported(ga, da[:, 0], st, T) is not None
+        out = pkg.CSPN_new.AffinityPropagate(T, 3)(ga, da, dev(s))
+    out.backward(dev(cot))
+    close = lambda a, b, tol: float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max()))   # noqa: E731
+    assert close(ga.grad.cpu().numpy(), wg, 5e-4) and close(da.grad.cpu().numpy(), wd, 5e-5)
+    F.check_resident_errors()
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (2, 37, 8, 7), (5, 60, 64, 9)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_resident_reverse_sweep_equals_multi_launch(B, H, W, T, sparse, c_oracle):
+    """cspn3_transposed_resident (the backward's reverse sweep with the transposed taps resident in registers) against
+    cspn_propagate_transposed on the same tap volume and cotangent: every G_t plane bit for bit."""
+    g, d, s = c_oracle.synthetic_inputs(170 + B + T, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    cot = dev(c_oracle.hash_normal(171, 9, (B, H, W)))
+    with torch.no_grad():
+        w8, _, _ = F.cspn3_prepare(dev(g))
+    sp = dev(s)[:, 0].contiguous() if sparse else None
+    with resident("off"):
+        _, ref = F._reverse_sweep(w8, 3, T, sp, cot, None)
+    with resident("on"):
+        _, out = F._reverse_sweep(w8, 3, T, sp, cot, None)
+        direct = F.transposed_resident(w8, cot, sp, T)
+    assert torch.equal(out, ref) and torch.equal(direct, ref)
+    F.check_resident_errors()
