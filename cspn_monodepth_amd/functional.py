@@ -26,14 +26,20 @@ class EventLog(list):
     Event objects are created (and recorded once, which is what actually allocates them) up front: creating
     them inside a timed region costs ~100 us each for the first few hundred."""
 
-    def __init__(self, n_pairs=0):
+    def __init__(self, n_pairs=0, every=1):
         super(EventLog, self).__init__()
+        self.every = max(1, int(every))      # sample every n-th instrumented call (two event records cost ~3 us of stream time)
+        self.calls = 0
         self.pool = []
         for _ in range(2 * int(n_pairs)):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.pool.append(ev)
         self.plan_cache = {}
+
+    def take(self):
+        self.calls += 1
+        return (self.calls - 1) % self.every == 0
 
     def pair(self):
         if len(self.pool) >= 2:
@@ -351,6 +357,8 @@ def propagate(w, d0, sparse, K, T, blend, keep_history=False, plan=None, valid_w
         if nbytes:
             work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     log = _EVENT_LOG
+    if log is not None and not log.take():
+        log = None
     with _device_guard(dev):
         if log is not None:
             ev0, ev1 = log.pair()
@@ -401,6 +409,8 @@ def propagate_scored(w, d0, sparse, K, T, blend, target, acc, plan=None, valid_w
     nbytes = L.cspn_propagate_workspace_bytes(B, H, W, int(T), _dt(d0), 0)
     work = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
     log = _EVENT_LOG
+    if log is not None and not log.take():
+        log = None
     with _device_guard(dev):
         if log is not None:
             ev0, ev1 = log.pair()
@@ -469,6 +479,8 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
         if nbytes:
             work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     log = _EVENT_LOG
+    if log is not None and not log.take():
+        log = None
     with _device_guard(dev):
         if log is not None:
             ev0, ev1 = log.pair()
@@ -599,6 +611,8 @@ def _resident_launch(dev, B, H, W, T, launch):
     the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call."""
     L = _lib.lib()
     log = _EVENT_LOG
+    if log is not None and not log.take():
+        log = None
     with _RES_LOCK:
         st = _resident_state(dev)
         if st["host_err_np"][0] != 0:
