@@ -54,22 +54,53 @@ struct ResArgs {
     unsigned long long* dbg;  // developer probe: [grid][16] wall-clock stamps (100 MHz) per workgroup, or null
 };
 
-__device__ __forceinline__ void st4_dev(float* p, float a, float b, float c, float d) {
+__device__ __forceinline__ void st4_dev(float* base, unsigned elem, float a, float b, float c, float d) {
     // ONE 16-byte device-scope store (global_store_dwordx4 ... sc1): visible to every XCD once vmcnt drops.  Written as
     // asm because the compiler only offers <= 8-byte atomics, and two 8-byte stores per quad touch every 64-byte line
     // twice with half masks (PMC: 2x the written bytes).  The caller waits with s_waitcnt vmcnt(0) before it signals.
+    // `base` is wave-uniform (the image's exchange plane): SGPR base + 32-bit VGPR byte offset, no 64-bit address math.
     const v4f v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(elem * 4u), "v"(v), "s"(base) : "memory");
 }
-__device__ __forceinline__ float4 ld4_dev(const float* p) {
-    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {      // a wave-uniform pointer, pinned to an SGPR pair
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// element `e` of a wave-uniform plane as SGPR base + 32-bit VGPR BYTE offset (planes stay below 2^30 elements: the host
+// checks), so that no load / store of the kernel needs 64-bit address arithmetic or an address register pair
+// The result is typed as a GLOBAL (address space 1) pointer: a pointer rebuilt from integers is otherwise generic, and a
+// flat_load counts on vmcnt AND lgkmcnt and may return out of order — every wait after one becomes vmcnt(0).
+#define GLB __attribute__((address_space(1)))
+typedef GLB char* gptr;
+__device__ __forceinline__ gptr at32(const float* base, unsigned e) {
+    return (gptr) reinterpret_cast<unsigned long long>(base) + (e << 2);
+}
+__device__ __forceinline__ float4 ld4(gptr p) {
+    const v4f v = *reinterpret_cast<const GLB v4f*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ld1(gptr p) { return *reinterpret_cast<const GLB float*>(p); }
+__device__ __forceinline__ void st4(gptr p, float4 v) {
+    const v4f w = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<GLB v4f*>(p) = w;
+}
+__device__ __forceinline__ float4 ld4_dev(gptr p) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
                        __uint_as_float((unsigned)(hi >> 32)));
 }
-__device__ __forceinline__ float ld1_dev(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ float ld1_dev(gptr p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const GLB unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+
+// The two depth buffers of the step loop sit a COMPILE-TIME distance apart (RES_PP floats; the second one starts there
+// whatever the region size): with the step loop unrolled by two, "the other buffer" is then an immediate offset of the
+// ds_read / ds_write instead of a second set of row addresses (7 VGPRs the 256-register instances do not have), and no
+// pointer is swapped per step.  65408 bytes + the largest row-relative offset still fit the 16-bit offset field.
+constexpr int RES_PP = 16352;
 
 // CLEAN = 1: the host verified that every region of the launch lies inside the image (shifted regions, image at least one
 // region large, no row padding): the step body carries no zero-padding selects.  A launch-level property, so that each
@@ -105,8 +136,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
     stamp();
 
-    const float* __restrict__ din0 = a.d0 + (size_t)b * HW;
-    const float* __restrict__ spg = BLEND ? a.sparse + (size_t)b * HW : nullptr;
+    const float* __restrict__ din0 = uniform_ptr(a.d0 + (size_t)b * HW);
+    const float* __restrict__ spg = BLEND ? uniform_ptr(a.sparse + (size_t)b * HW) : nullptr;
 
     // ---- ownership: strip (sx, sy) = NQ vertically consecutive quads of the weight region (tile + halo) -------------
     const int wq = a.wq, wr = a.wr;
@@ -132,46 +163,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // ---- 0. the coarse-depth region of phase 0 is requested FIRST: loads return in order, so it lands in LDS while the
     //         (8x larger) guidance stream below is still in flight, and the staging costs no round trip of its own
     const int dr = a.dr, ls = a.ls;
-    float* cur = lds;
-    float* nxt = lds + (size_t)dr * ls;
+    float* const cur = lds;                    // buffer 0: where every phase starts (phases have an even number of steps)
+    float* const nxt = lds + RES_PP;
     const int yd0 = ry0 - R;                   // image y of depth-region row 0
     const int xd0 = rx0 - 4;                   // image x of LDS column 0
     float4 st0[NQ + 1];                        // dr * wq <= (NQ + 1) * NTHREADS quads
-    int at0[NQ + 1];
     unsigned st0_in = 0;
+    // quad u * NTHREADS + tid of the region, row-major: (row, qx) advances by a uniform (NTHREADS / wq, NTHREADS % wq) per
+    // u — no per-quad division, whose temporaries the register-bound derive cannot afford
+    const int step_r = NTHREADS / wq, step_q = NTHREADS - step_r * wq;
+    {
+    int row = sy, qx = sx;
 #pragma unroll
     for (int u = 0; u <= NQ; ++u) {
-        const int idx = u * NTHREADS + tid;
-        const int row = idx / wq, qx = idx - row * wq;
         const int y = yd0 + row, x = xd0 + 4 + 4 * qx;
-        const bool valid = idx < dr * wq;
+        const bool valid = row < dr;
         const bool in = valid && (y >= 0 && y < H && x >= 0 && x < a.Wv);
         if (in) st0_in |= 1u << u;
-        st0[u] = ld4(din0 + (in ? (unsigned)(y * W + x) : 0u));
+        st0[u] = ld4(at32(din0, in ? (unsigned)(y * W + x) : 0u));
         if (TRANS && BLEND) {                          // PREMASK: the sweep starts from (1-m) G_T
-            const float4 sp = ld4(spg + (in ? (unsigned)(y * W + x) : 0u));
+            const float4 sp = ld4(at32(spg, in ? (unsigned)(y * W + x) : 0u));
             st0[u].x *= 1.f - sgnf(sp.x); st0[u].y *= 1.f - sgnf(sp.y); st0[u].z *= 1.f - sgnf(sp.z); st0[u].w *= 1.f - sgnf(sp.w);
         }
-        at0[u] = valid ? row * ls + 4 + 4 * qx : -1;
+        row += step_r; qx += step_q;
+        if (qx >= wq) { qx -= wq; ++row; }
+    }
     }
     float ring0 = 0.f;
-    int ring0_at = -1;
     bool ring0_in = false;
     if (tid < dr * 2 * R) {
         const int row = tid / (2 * R), c = tid - row * (2 * R);
         const int lc = (c < R) ? (4 - R + c) : (4 + 4 * wq + (c - R));
         const int y = yd0 + row, x = xd0 + lc;
         ring0_in = (y >= 0 && y < H && x >= 0 && x < a.Wv);
-        ring0 = ld1(din0 + (ring0_in ? (unsigned)(y * W + x) : 0u));
-        if (TRANS && BLEND) ring0 *= 1.f - sgnf(ld1(spg + (ring0_in ? (unsigned)(y * W + x) : 0u)));
-        ring0_at = row * ls + lc;
+        ring0 = ld1(at32(din0, ring0_in ? (unsigned)(y * W + x) : 0u));
+        if (TRANS && BLEND) ring0 *= 1.f - sgnf(ld1(at32(spg, ring0_in ? (unsigned)(y * W + x) : 0u)));
     }
 
     // ---- 1. weights of the owned quads, derived once from the raw guidance (CSPN_new.py:29-70, :124-127) -------------
     float wreg[NQ][NT][4];
     unsigned in_img = 0, interior = 0;
-    float* const md_lds = lds + (size_t)2 * a.dr * a.ls;          // private slots: m * d0 of the owned quads
-    const float* __restrict__ gq = a.g + (size_t)b * a.g_bs;
+    float* const md_lds = lds + RES_PP + (size_t)a.dr * a.ls;     // private slots: m * d0 of the owned quads
+    const float* __restrict__ gq = uniform_ptr(a.g + (size_t)b * a.g_bs);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j: the aligned quad of row y+dy gives three of
     // the four shifted values, the fourth is the neighbouring lane's quad (DPP) or, at strip ends / wave edges, a scalar.
@@ -182,7 +215,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // scalars are requested right behind quad i's planes and the arithmetic below can start on quad 0 while quads 1.. stream.)
     float edge[NQ][6];                     // [0..2]: column xq-1 of the dx<0 taps (j = 0,3,5); [3..5]: column xq+4 of the dx>0 taps (j = 2,4,7)
     const unsigned ucs = (unsigned)a.g_cs;
-    unsigned edge_ok = 0;                  // bit i*6+t: edge[i][t] holds a pixel inside the image
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int r = r0 + i, y = yq0 + i;
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         for (int j = 0; j < NT; ++j) {
             const int lin = j < 4 ? j : j + 1;
             const int d = lin / 3;
-            const float4 v = ld4(gq + ((unsigned)(7 - j) * ucs + orow[d]));
+            const float4 v = ld4(at32(gq, (unsigned)(7 - j) * ucs + orow[d]));
             wreg[i][j][0] = rokv[d] ? v.x : 0.f; wreg[i][j][1] = rokv[d] ? v.y : 0.f;
             wreg[i][j][2] = rokv[d] ? v.z : 0.f; wreg[i][j][3] = rokv[d] ? v.w : 0.f;
         }
@@ -216,29 +248,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 const int d = lin / 3;
                 const int xx = lft ? xq - 1 : xq + 4;
                 const bool c = rokv[d] && (lft ? fix_left : fix_right) && xx >= 0 && xx < W;
-                if (c) edge_ok |= 1u << (i * 6 + t);
                 // raw value only: consuming it here would make this block wait for the quad's loads (in-order return)
-                edge[i][t] = ld1(gq + ((unsigned)(7 - j) * ucs + (c ? orow[d] + (unsigned)(xx - xq) : 0u)));
+                edge[i][t] = ld1(at32(gq, (unsigned)(7 - j) * ucs + (c ? orow[d] + (unsigned)(xx - xq) : 0u)));
             }
         }
     }
     // park the depth region (its loads were requested before the guidance: only those are waited for here)
+    // (the LDS slots are worked out here, from an opaque copy of the thread id: the derive above is register-bound, and a
+    // spilled value reloaded in the middle of it waits for every outstanding guidance load)
+    int tidk = tid, prow = sy, pqx = sx;
+    asm volatile("" : "+v"(tidk), "+v"(prow), "+v"(pqx));
 #pragma unroll
     for (int u = 0; u <= NQ; ++u) {
         const bool in = (st0_in >> u) & 1u;
-        if (at0[u] >= 0)
-            *reinterpret_cast<float4*>(&cur[at0[u]]) = make_float4(in ? st0[u].x : 0.f, in ? st0[u].y : 0.f, in ? st0[u].z : 0.f, in ? st0[u].w : 0.f);
+        if (prow < dr)
+            *reinterpret_cast<float4*>(&cur[prow * ls + 4 + 4 * pqx]) = make_float4(in ? st0[u].x : 0.f, in ? st0[u].y : 0.f, in ? st0[u].z : 0.f, in ? st0[u].w : 0.f);
+        prow += step_r; pqx += step_q;
+        if (pqx >= wq) { pqx -= wq; ++prow; }
     }
-    if (ring0_at >= 0) { cur[ring0_at] = ring0_in ? ring0 : 0.f; nxt[ring0_at] = 0.f; }
+    if (tidk < dr * 2 * R) {
+        const int row = tidk / (2 * R), c = tidk - row * (2 * R);
+        const int ring0_at = row * ls + ((c < R) ? (4 - R + c) : (4 + 4 * wq + (c - R)));
+        cur[ring0_at] = ring0_in ? ring0 : 0.f; nxt[ring0_at] = 0.f;
+    }
     // The ring ROWS of the second buffer are never computed either.  With the regions shifted into the image they ARE the
     // zero padding above / below the image for edge tiles, so they must read as exactly 0 in both buffers (LDS keeps
     // whatever the previous kernel left there).
-    for (int c = tid; c < 2 * ls; c += NTHREADS) nxt[(c < ls ? 0 : (dr - 1) * ls - ls) + c] = 0.f;
+    for (int c = tidk; c < 2 * ls; c += NTHREADS) nxt[(c < ls ? 0 : (dr - 1) * ls - ls) + c] = 0.f;
+    // sparse blend: the masks of the owned quads are requested now, behind the guidance (loads return in order: they are
+    // there when the last quad's weights are), into the registers the parked depth quads just left
+    float4 mraw[BLEND ? NQ : 1];
+    if (BLEND) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const bool ok = (in_img >> i) & 1u;
+            mraw[i] = ld4(at32(spg, ok ? (unsigned)((yq0 + i) * W + xq) : 0u));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int r = r0 + i;
         const bool ok = (in_img >> i) & 1u;
-        const size_t off = (size_t)(ok ? yq0 + i : 0) * W + (ok ? xq : 0);
+        // does edge[i][t] hold a pixel inside the image?  (recomputed: a bit mask built while the loads are issued is one
+        // more live register there)
+        auto edge_in = [&](int j, bool lft) -> bool {
+            const int lin = j < 4 ? j : j + 1;
+            const int row = yq0 + i + lin / 3 - 1;
+            return ok && row >= 0 && row < H && (lft ? xq - 1 >= 0 : xq + 4 < W);
+        };
+        const unsigned off = ok ? (unsigned)((yq0 + i) * W + xq) : 0u;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int lin = j < 4 ? j : j + 1;
@@ -247,12 +305,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             if (dx < 0) {
                 const int t = j == 0 ? 0 : (j == 3 ? 1 : 2);
                 const float nb = dpp_from_prev_lane(q3);
-                const float lf = fix_left ? (((edge_ok >> (i * 6 + t)) & 1u) ? edge[i][t] : 0.f) : nb;
+                const float lf = fix_left ? (edge_in(j, true) ? edge[i][t] : 0.f) : nb;
                 wreg[i][j][0] = TRANS ? lf : fabsf(lf); wreg[i][j][1] = TRANS ? q0 : fabsf(q0); wreg[i][j][2] = TRANS ? q1 : fabsf(q1); wreg[i][j][3] = TRANS ? q2 : fabsf(q2);
             } else if (dx > 0) {
                 const int t = j == 2 ? 3 : (j == 4 ? 4 : 5);
                 const float nb = dpp_from_next_lane(q0);
-                const float rt = fix_right ? (((edge_ok >> (i * 6 + t)) & 1u) ? edge[i][t] : 0.f) : nb;
+                const float rt = fix_right ? (edge_in(j, false) ? edge[i][t] : 0.f) : nb;
                 wreg[i][j][0] = TRANS ? q1 : fabsf(q1); wreg[i][j][1] = TRANS ? q2 : fabsf(q2); wreg[i][j][2] = TRANS ? q3 : fabsf(q3); wreg[i][j][3] = TRANS ? rt : fabsf(rt);
             } else {
                 wreg[i][j][0] = TRANS ? q0 : fabsf(q0); wreg[i][j][1] = TRANS ? q1 : fabsf(q1); wreg[i][j][2] = TRANS ? q2 : fabsf(q2); wreg[i][j][3] = TRANS ? q3 : fabsf(q3);
@@ -281,12 +339,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         }
         if (MODE == 2 && ((interior >> i) & 1u)) {   // publish before the blend is folded in: the backward wants w and S themselves
             store_taps_quad<NT>(a.w_out + (size_t)b * NT * HW, off, HW, wreg[i]);
-            st4(a.s_out + (size_t)b * HW + off, make_float4(Sq[0], Sq[1], Sq[2], Sq[3]));
+            st4(at32(uniform_ptr(a.s_out + (size_t)b * HW), off), make_float4(Sq[0], Sq[1], Sq[2], Sq[3]));
         }
+    }
+    // the blend is folded in by a second pass: the masks were requested BEHIND the guidance, so touching the first one
+    // waits for the whole stream — after the weight arithmetic, which consumes the stream as it arrives, that wait is free
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int r = r0 + i;
+        const bool ok = (in_img >> i) & 1u;
         if (BLEND && r < wr) {
             // (1-m) u + m d0  ==  sum_j ((1-m) w_j) d_j + m d0 with 1-m in {0,1,2}: exact, so bit-identical (CSPN_new.py:90)
-            const float4 mraw = ld4(spg + off);                   // off = 0 for quads outside the image
-            const float4 m = make_float4(ok ? sgnf(mraw.x) : 0.f, ok ? sgnf(mraw.y) : 0.f, ok ? sgnf(mraw.z) : 0.f, ok ? sgnf(mraw.w) : 0.f);
+            const float4 m = make_float4(ok ? sgnf(mraw[i].x) : 0.f, ok ? sgnf(mraw[i].y) : 0.f, ok ? sgnf(mraw[i].z) : 0.f, ok ? sgnf(mraw[i].w) : 0.f);
             const float omq[4] = {1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w};
             if (TRANS) {                               // PREMASK: the private plane holds 1-m, applied to every step's result
                 *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) = make_float4(omq[0], omq[1], omq[2], omq[3]);
@@ -295,19 +359,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) wreg[i][j][e] *= omq[e];
-                const float4 v = ld4(din0 + off);
-                *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) =
-                    make_float4(ok ? m.x * v.x : 0.f, ok ? m.y * v.y : 0.f, ok ? m.z * v.z : 0.f, ok ? m.w * v.w : 0.f);
+                // the private slot receives m now and becomes m * d0 once the depth region is staged (the owned quads of
+                // d0 are read from LDS there anyway: no second global load, no exposed round trip)
+                *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) = m;
             }
         }
     }
 
     stamp();                                   // weights derived
+    // Everything below addresses through LATE, opaque copies of the strip coordinates: row / pixel offsets of the step loop,
+    // the staging and the epilogue are then computed here, after the derive — computed early they sit in registers the
+    // derive needs, get spilled, and every scratch reload in the derive waits for ALL outstanding guidance loads
+    // (s_waitcnt vmcnt(0): loads return in order), which serialises the load stream and the weight arithmetic.
+    int r0L = r0, sxL = sx, yq0L = yq0, xqL = xq;
+    asm volatile("" : "+v"(r0L), "+v"(sxL), "+v"(yq0L), "+v"(xqL));
     // ---- 2. phases of S steps; between phases the tile borders travel through the exchange planes ---------------------
-    const bool active = (r0 < wr);
-    const int cb = 4 + 4 * sx;
-    float* __restrict__ dout = HIST ? nullptr : a.out + (size_t)b * HW;
-    float* hist_step = HIST ? a.hist + (size_t)b * HW : nullptr;      // plane of the step being computed (uniform)
+    const bool active = (r0L < wr);
+    const int cb = 4 + 4 * sxL;
+    float* __restrict__ dout = HIST ? nullptr : uniform_ptr(a.out + (size_t)b * HW);
+    float* hist_step = HIST ? uniform_ptr(a.hist + (size_t)b * HW) : nullptr;      // plane of the step being computed (uniform)
     const int n_phase = (a.T + a.S - 1) / a.S;
     const int tile_global = b * tiles_per_img + trem;
     float own[NQ][4];
@@ -317,10 +387,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
         const bool last_phase = (p == n_phase - 1);
         // -- stage the depth region (weight region + 1 ring).  Phase 0: everything from the coarse depth.  Later phases:
         //    the tile's own interior is already in LDS (`cur`), only the halo comes from the neighbours' published borders
-        const float* __restrict__ xin = a.xbuf + (size_t)((p + 1) & 1) * plane + (size_t)b * HW;   // written in phase p-1
+        const float* __restrict__ xin = uniform_ptr(a.xbuf + (size_t)((p + 1) & 1) * plane + (size_t)b * HW);   // written in phase p-1
         if (p > 0) {
             // halo quads only: the full rows above and below the tile rows, the quads left and right of the tile columns.  All
             // device-scope loads of a batch are requested before the first one is consumed (branch-free: safe address + select).
+            int tidp = tid;                                    // opaque copy: the per-thread halo addressing below is recomputed
+            asm volatile("" : "+v"(tidp));                     // every phase instead of living (spilled) across the step loop
             const int tq_in = min(a.tw, rx0 + 4 * wq - x0) >> 2;   // tile columns / rows that lie inside the region (the last
             const int th_in = min(a.th, ry0 + wr - y0);            // tile of an image may be cut short by the image edge)
             const int nl = (x0 - rx0) >> 2;                    // quads left of the tile columns inside the region
@@ -333,12 +405,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             // the 1-pixel ring columns left / right of the region: one scalar per row and side
             float ring_v = 0.f;
             int ring_at = -1;
-            if (tid < dr * 2 * R) {
-                const int row = tid / (2 * R), c = tid - row * (2 * R);
+            if (tidp < dr * 2 * R) {
+                const int row = tidp / (2 * R), c = tidp - row * (2 * R);
                 const int lc = (c < R) ? (4 - R + c) : (4 + 4 * wq + (c - R));
                 const int y = yd0 + row, x = xd0 + lc;
                 const bool in = (y >= 0 && y < H && x >= 0 && x < a.Wv);
-                const float v = ld1_dev(xin + (in ? (size_t)y * W + x : (size_t)0));
+                const float v = ld1_dev(at32(xin, in ? (unsigned)(y * W + x) : 0u));
                 ring_v = in ? v : 0.f;
                 ring_at = row * ls + lc;
             }
@@ -347,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 int at[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int h = base + u * NTHREADS + tid;
+                    const int h = base + u * NTHREADS + tidp;
                     int row, qx;
                     if (h < n_top) { row = h / wq; qx = h - row * wq; }
                     else if (h < n_top + n_bot) { const int h2 = h - n_top; row = h2 / wq; qx = h2 - row * wq; row += nrow_t + th_in; }
@@ -362,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     const int y = yd0 + row, x = xd0 + 4 + 4 * qx;
                     const bool valid = h < n_halo;
                     const bool in = valid && y >= 0 && y < H && x >= 0 && x < a.Wv;
-                    const float4 v = ld4_dev(xin + (in ? (size_t)y * W + x : (size_t)0));
+                    const float4 v = ld4_dev(at32(xin, in ? (unsigned)(y * W + x) : 0u));
                     hv[u] = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
                     at[u] = valid ? row * ls + 4 + 4 * qx : -1;
                 }
@@ -371,29 +443,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     if (at[u] >= 0) *reinterpret_cast<float4*>(&cur[at[u]]) = hv[u];
             }
             if (ring_at >= 0) { cur[ring_at] = ring_v; nxt[ring_at] = 0.f; }
-            for (int c = tid; c < 2 * ls; c += NTHREADS) nxt[(c < ls ? 0 : (dr - 1) * ls - ls) + c] = 0.f;   // see phase 0
+            for (int c = tidp; c < 2 * ls; c += NTHREADS) nxt[(c < ls ? 0 : (dr - 1) * ls - ls) + c] = 0.f;   // see phase 0
         }
         __syncthreads();
 
-        if (active) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {             // rows past the region read the clamped last row; they are never stored
+            int drow = r0L + i + R;
+            drow = drow < dr ? drow : dr - 1;
+            const v4f mid = *(lds_cv4f_ptr)(cur + drow * ls + cb);
+            own[i][0] = mid.x; own[i][1] = mid.y; own[i][2] = mid.z; own[i][3] = mid.w;
+        }
+        if (BLEND && !TRANS && p == 0) {           // private slots: m -> m * d0 (own = d0 here)
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                int drow = r0 + i + R;
-                if (NQ > 1) drow = drow < dr ? drow : dr - 1;
-                const v4f mid = *(lds_cv4f_ptr)(cur + drow * ls + cb);
-                own[i][0] = mid.x; own[i][1] = mid.y; own[i][2] = mid.z; own[i][3] = mid.w;
+                if (r0L + i < wr) {
+                    float4* slot = reinterpret_cast<float4*>(md_lds + ((r0L + i) * wq + sxL) * 4);
+                    const float4 m = *slot;
+                    // plain products, as the reference's  m * d0  (0 * inf = nan spreads like there); quads outside the
+                    // image hold m = 0 and a zero-padded d0
+                    *slot = make_float4(m.x * own[i][0], m.y * own[i][1], m.z * own[i][2], m.w * own[i][3]);
+                }
             }
         }
         // One propagation step on the LDS tile.  FINAL (the very last step of the forward) is peeled into its own copy so
         // that the target quads of the fused metrics are only live there, not across the hot loop.
-        auto step = [&](auto final_c) __attribute__((always_inline)) {
+        auto step = [&](auto final_c, auto on_c, auto par_c, int final_par) __attribute__((always_inline)) {
             constexpr bool FINAL = decltype(final_c)::value;
-            if (active) {
+            constexpr int PAR = decltype(par_c)::value;       // buffer this step reads (the final step: `final_par`)
+            if (decltype(on_c)::value) {
                 float win[NQ + 2 * R][WIN];
+                const float* const rd = FINAL ? lds + final_par * RES_PP : lds + PAR * RES_PP;
+                float* const wrb = lds + (1 - PAR) * RES_PP;
+                // the peeled final step runs once: its row / pixel offsets are recomputed from opaque copies instead of being
+                // kept (spilled) across the hot loop
+                int r0x = r0L, yqx = yq0L;
+                if (FINAL) asm volatile("" : "+v"(r0x), "+v"(yqx));
                 auto row_ptr = [&](int rr) -> const float* {
-                    int drow = r0 + rr;
-                    if (NQ > 1) drow = drow < dr ? drow : dr - 1;
-                    return cur + drow * ls + cb;
+                    int drow = r0x + rr;
+                    drow = drow < dr ? drow : dr - 1;
+                    return rd + drow * ls + cb;
                 };
 #pragma unroll
                 for (int rr = 0; rr < NQ + 2 * R; ++rr) {
@@ -422,7 +511,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 }
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
-                    if (r0 + i < wr) {
+                    // rows past the region (r0L + i >= wr, only in the last row group) are computed too — their taps are
+                    // zero — and only their LDS store is masked: a branch around the arithmetic costs exec-masked copies of
+                    // the carried quads on every step
+                    {
                         float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int dy = -1; dy <= 1; ++dy)
@@ -436,7 +528,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                             }
                         float keep[4];                 // the state carried to the next step
                         if (BLEND) {
-                            const float4 m4 = *reinterpret_cast<const float4*>(md_lds + ((r0 + i) * wq + sx) * 4);
+                            const float4 m4 = *reinterpret_cast<const float4*>(md_lds + (min(r0L + i, wr - 1) * wq + sxL) * 4);
                             if (TRANS) {
                                 keep[0] = m4.x * u[0]; keep[1] = m4.y * u[1]; keep[2] = m4.z * u[2]; keep[3] = m4.w * u[3];
                             } else {
@@ -452,36 +544,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                             for (int e = 0; e < 4; ++e)
                                 if (!((in_img >> i) & 1u) || e >= nval) { u[e] = 0.f; keep[e] = 0.f; }   // zero padding stays exactly zero
                         }
-                        if (!FINAL)
-                            *reinterpret_cast<float4*>(&nxt[(r0 + i + R) * ls + cb]) = make_float4(keep[0], keep[1], keep[2], keep[3]);
+                        if (!FINAL && r0L + i < wr)
+                            *reinterpret_cast<float4*>(&wrb[(r0L + i + R) * ls + cb]) = make_float4(keep[0], keep[1], keep[2], keep[3]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) own[i][e] = keep[e];
                         if (HIST) {
-                            if ((interior >> i) & 1u) st4(hist_step + (unsigned)((yq0 + i) * W + xq), make_float4(u[0], u[1], u[2], u[3]));
+                            if ((interior >> i) & 1u) st4(at32(hist_step, (unsigned)((yq0L + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
                         } else if (FINAL && ((interior >> i) & 1u)) {
-                            st4(dout + (size_t)(yq0 + i) * W + xq, make_float4(u[0], u[1], u[2], u[3]));
+                            st4(at32(dout, (unsigned)((yqx + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
                         }
                     }
                 }
             }
             if (HIST) hist_step += plane;
-            if (!FINAL) {
-                __syncthreads();
-                float* t = cur; cur = nxt; nxt = t;
-            }
+            if (!FINAL) __syncthreads();
         };
         stamp();                               // depth staged
         const int plain_steps = last_phase ? steps - 1 : steps;
-        for (int s = 0; s < plain_steps; ++s) step(std::false_type{});
-        if (last_phase) step(std::true_type{});
+        // Wavefronts without a single owned row (the tail of the last row group) only keep the barriers company.  The test is
+        // wave-uniform (a scalar branch), and the step loop sits INSIDE it: a per-step `if (active)` makes every carried quad
+        // a phi of "old" and "new" that is resolved with 20 v_mov per step.  Idle lanes of a working wavefront run the
+        // arithmetic on clamped rows with zero taps; only their stores are masked.  Two steps per trip let the carried
+        // quads alternate between two register sets.
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        if (__ballot(active) != 0ull) {
+            int s = 0;
+            for (; s + 1 < plain_steps; s += 2) {
+                step(std::false_type{}, std::true_type{}, P0{}, 0);
+                step(std::false_type{}, std::true_type{}, P1{}, 0);
+            }
+            if (s < plain_steps) step(std::false_type{}, std::true_type{}, P0{}, 0);
+            if (last_phase) step(std::true_type{}, std::true_type{}, P0{}, plain_steps & 1);
+        } else {
+            for (int s = 0; s < plain_steps; ++s) step(std::false_type{}, std::false_type{}, P0{}, 0);
+            if (last_phase) step(std::true_type{}, std::false_type{}, P0{}, 0);
+        }
         stamp();                               // steps of the phase done
         if (!last_phase) {
             // -- publish the interior quads (device scope), then the phase flag; wait for the 8 neighbouring tiles
-            float* __restrict__ xout = a.xbuf + (size_t)(p & 1) * plane + (size_t)b * HW;
+            float* __restrict__ xout = uniform_ptr(a.xbuf + (size_t)(p & 1) * plane + (size_t)b * HW);
             if (active) {
+                // (opaque to the optimiser: the per-quad offsets are recomputed here, not hoisted out of the phase loop into
+                // registers the step loop needs — they would be spilled and reloaded from scratch every phase)
+                unsigned o0 = (unsigned)(yq0L * W + xqL);
+                asm volatile("" : "+v"(o0));
 #pragma unroll
                 for (int i = 0; i < NQ; ++i)
-                    if ((interior >> i) & 1u) st4_dev(xout + (size_t)(yq0 + i) * W + xq, own[i][0], own[i][1], own[i][2], own[i][3]);
+                    if ((interior >> i) & 1u) st4_dev(xout, o0 + (unsigned)(i * W), own[i][0], own[i][1], own[i][2], own[i][3]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's device-scope stores have landed
             __syncthreads();                                       // ... and so have everybody else's in the workgroup
@@ -526,10 +636,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             // the target quads are requested only now: the weight registers are dead, nothing spills, and the one exposed
             // round trip costs less than carrying NQ quads through the final step did
             float4 scored_t[NQ];
+            const float* tgt_b = uniform_ptr(a.target + (size_t)b * HW);
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const bool in = (interior >> i) & 1u;
-                scored_t[i] = ld4(a.target + (size_t)b * HW + (in ? (size_t)(yq0 + i) * W + xq : (size_t)0));
+                scored_t[i] = ld4(at32(tgt_b, in ? (unsigned)((yq0L + i) * W + xqL) : 0u));
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -542,7 +653,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 }
             }
         }
-        float* part = lds + (size_t)2 * a.dr * a.ls + (size_t)(BLEND ? 1 : 0) * a.wr * 4 * a.wq;
+        float* part = lds + RES_PP + (size_t)a.dr * a.ls + (size_t)(BLEND ? 1 : 0) * a.wr * 4 * a.wq;
         const int wave = tid >> 6;
         __syncthreads();
 #pragma unroll
@@ -582,6 +693,12 @@ int cu_count() {
     return prop.multiProcessorCount;
 }
 
+// LDS of one workgroup: buffer 0 in the first RES_PP floats, buffer 1 behind it, then the private m * d0 quads (sparse
+// blend) and the 10 x 16 partial sums of the fused metrics.
+size_t res_lds_bytes(int dr, int ls, int wr, int wq, int blend) {
+    return ((size_t)RES_PP + (size_t)dr * ls + (size_t)(blend ? 1 : 0) * wr * 4 * wq + 16 * 10) * sizeof(float);
+}
+
 // Mirror of the kernel's region placement: does every region of every tile lie inside the (valid part of the) image?
 bool regions_inside_image(const ResGeom& g, int H, int W, int Wv) {
     if (Wv != W) return false;
@@ -611,6 +728,7 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
         const int Se = S > T ? T : S;
         const int hyw = Se - 1, hxw = round_up4(Se - 1);
         const int phases = ceil_div(T, Se);
+        if (phases > 1 && (Se & 1)) continue;          // every phase must start in buffer 0 (see RES_PP)
         for (int tx = 1; tx <= 32; ++tx) {
             const int tw = round_up4(ceil_div(W, tx));
             if (tx > 1 && (tw < 16 || ceil_div(W, tw) != tx)) continue;
@@ -628,16 +746,19 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
                 const int nq = ceil_div(wr, rows_per_thread_col);
                 if (nq > RES_MAX_NQ) continue;
                 const int dr = wr + 2, ls = 4 * wq + 8;
-                const size_t ldsb = ((size_t)2 * dr * ls + (size_t)(blend ? 1 : 0) * wr * 4 * wq + 16 * 10) * sizeof(float);
+                if ((size_t)dr * ls > (size_t)RES_PP) continue;                      // one depth buffer per RES_PP slot
+                const size_t ldsb = res_lds_bytes(dr, ls, wr, wq, blend);
                 if (ldsb > 160 * 1024) continue;
                 int ipl = ncu / tiles;
                 if (ipl > B) ipl = B;
                 const int launches = ceil_div(B, ipl);
                 ResGeom cand{Se, tx, ty, tw, th, nq, wq, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, 0.0};
-                // per launch: derive (~2 steps' worth per quad) + T steps, each ~ (nq + 1.5) units (x 1.13 with the zero-padding
-                // selects of a launch whose regions stick out of the image); + exchange latency
-                const double step_units = (nq + 1.5) * (regions_inside_image(cand, H, W, W) ? 1.0 : 1.13);
-                const double cost = launches * ((T + 2.0) * step_units + 6.0 * (phases - 1));
+                // microseconds per launch, fitted on MI355X (profiles/r02_resident_vs_multilaunch.jsonl): launch + epilogue,
+                // derive (~2 us per quad of a thread), T steps (VALU-bound: 0.13 us per quad; x 1.13 with the zero-padding
+                // selects of a launch whose regions stick out of the image), and per phase boundary the publish / wait /
+                // halo staging (3 us + the border bytes)
+                const double pen = regions_inside_image(cand, H, W, W) ? 1.0 : 1.13;
+                const double cost = launches * (8.0 + 2.0 * nq + T * (0.13 * nq + 0.1) * pen + (phases - 1) * (3.0 + 0.6 * nq));
                 if (!found || cost < best->cost) {
                     found = true;
                     *best = ResGeom{Se, tx, ty, tw, th, nq, wq, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, cost};
@@ -771,10 +892,10 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         g.wq = (g.tw + 2 * g.hxw) / 4; g.wr = g.th + 2 * g.hyw;
         g.dr = g.wr + 2; g.ls = 4 * g.wq + 8;
         g.nq = g.wq > 0 && g.wq <= RES_THREADS ? ceil_div(g.wr, RES_THREADS / g.wq) : RES_MAX_NQ + 1;
-        g.lds_bytes = ((size_t)2 * g.dr * g.ls + (size_t)(blend ? 1 : 0) * g.wr * 4 * g.wq + 16 * 10) * sizeof(float);
+        g.lds_bytes = res_lds_bytes(g.dr, g.ls, g.wr, g.wq, blend);
         g.imgs_per_launch = rp.images_per_launch;
         const int phases = ceil_div(T, Se);
-        if ((g.tw & 3) || g.nq > RES_MAX_NQ || g.lds_bytes > 160 * 1024 || g.tiles_x * g.tw < W || g.tiles_y * g.th < H ||
+        if ((g.tw & 3) || g.nq > RES_MAX_NQ || g.lds_bytes > 160 * 1024 || (size_t)g.dr * g.ls > (size_t)RES_PP || (phases > 1 && (Se & 1)) || g.tiles_x * g.tw < W || g.tiles_y * g.th < H ||
             (long)g.imgs_per_launch * g.tiles_x * g.tiles_y > ncu ||
             (phases > 1 && ((g.tiles_x > 1 && g.tw < 2 * g.hxw) || (g.tiles_y > 1 && g.th < 2 * g.hyw))))
             return fail("cspn3_forward_resident: the plan does not fit this problem / device (use cspn3_resident_plan)");

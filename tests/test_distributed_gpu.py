@@ -47,5 +47,8 @@ def test_bench_two_ranks_on_one_gpu_kitti():
     assert d2["value"] > 0 and abs(d2["value"] - 8 * 4 / (d2["ms_per_step"] * 4 / 1e3)) / d2["value"] < 1e-6
     m1, m2 = d1["metrics_check"], d2["metrics_check"]
     assert m1["count"] == m2["count"] and m1["count"] > 0
+    # the refined depth is bit-identical between the schedules (tests/test_hip_resident.py); the fused metric sums are
+    # fp32 per thread before they meet in fp64, and the single-process run (weight-resident plan) groups the pixels of a
+    # thread differently from the shards' multi-launch plan: equal up to summation order
     for k in ("rmse", "absrel", "delta1"):
-        assert abs(m1[k] - m2[k]) <= 1e-9 * abs(m1[k]), (k, m1[k], m2[k])
+        assert abs(m1[k] - m2[k]) <= 1e-6 * abs(m1[k]), (k, m1[k], m2[k])
