@@ -92,7 +92,7 @@ def load_pmc_traffic(tag, schedule="fused"):
     out["source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, gfx950-corrected%s)" % (
         os.path.basename(files[0]), "; measured at commit %s" % j["commit"] if j.get("commit") else "")
     try:
-        out["stale"] = (j.get("source_digest") != pkg._lib._source_digest([])) if j.get("source_digest") else None
+        out["stale"] = (j.get("source_digest") != pkg._lib.code_digest()) if j.get("source_digest") else None
     except Exception:
         out["stale"] = None
     pk = j.get("per_kernel", {})
@@ -128,7 +128,7 @@ def load_train_traffic(tag):
         per = {k: [v["hbm_bytes_corrected"], v["_dispatches_FETCH_SIZE"] / iters] for k, v in ks.items()}
         return {"bytes_per_step": sum(b * n for b, n in per.values()), "per_kernel": per,
                 "source": "profiles/%s%s" % (os.path.basename(files[0]), "; measured at commit %s" % j["commit"] if j.get("commit") else ""),
-                "stale": (j.get("source_digest") != pkg._lib._source_digest([])) if j.get("source_digest") else None}
+                "stale": (j.get("source_digest") != pkg._lib.code_digest()) if j.get("source_digest") else None}
     except Exception:
         return None
 
@@ -476,14 +476,27 @@ def main():
             step()
         pkg.evaluation.all_gather_metric_sums(sums)   # untimed: first use loads the reduction kernels / sets up RCCL
         sums.zero_()
+        # Rehearsal of the timed region's own sequence (fence -> instrumented steps -> gather -> fence), untimed: the first
+        # step issued right after a device-wide fence costs the host 90-240 us ONCE per process (lazy runtime state; 30 us
+        # from the second time on) — a fifth of a 20-step region, nothing of a 200-step one
+        F.set_event_log(F.EventLog(2, every=1))
+        fence()
+        step()
+        step()
+        pkg.evaluation.all_gather_metric_sums(sums)
+        fence()
+        sums.zero_()
         # HIP events around every 4th step only (two records cost ~3 us of stream time each step): still measured live
         # inside the timed region, `launches_timed` says how many launches the average is over
         events = F.EventLog(args.steps, every=4 if args.steps >= 20 else 1)
         F.set_event_log(events)
         fence()
+        dbg_host = [] if os.environ.get("BENCH_DEBUG") else None
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+            if dbg_host is not None:
+                dbg_host.append(time.perf_counter())
         t_loop = time.perf_counter()
         total, per_rank = pkg.evaluation.all_gather_metric_sums(sums)  # the only collective: 10 float64 per rank
         t_gather = time.perf_counter()
@@ -492,6 +505,13 @@ def main():
         if os.environ.get("BENCH_DEBUG") and rank == 0:
             print("debug: host loop %.2f ms, gather call %.2f ms, final fence %.2f ms" % (
                 (t_loop - t0) * 1e3, (t_gather - t_loop) * 1e3, (t1 - t_gather) * 1e3), file=sys.stderr)
+            print("debug: host us per step call: %s" % " ".join("%.0f" % ((b - a) * 1e6) for a, b in zip([t0] + dbg_host, dbg_host)),
+                  file=sys.stderr)
+            evs = list(events)
+            if len(evs) > 1:
+                print("debug: GPU us between sampled steps' starts: %s; sampled step durations: %s" % (
+                    " ".join("%.0f" % (evs[i][0].elapsed_time(evs[i + 1][0]) * 1e3) for i in range(len(evs) - 1)),
+                    " ".join("%.0f" % (e[0].elapsed_time(e[1]) * 1e3) for e in evs)), file=sys.stderr)
         F.set_event_log(None)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:

@@ -19,10 +19,21 @@
 // instead of hanging (include/cspn_hip.h: cspn3_forward_resident).
 //
 // Measured on MI355X (config 2: B=24, 228x304, T=24; profiles/r02_*): 2x5 tiles of 152x46 per image = 240 workgroups of
-// 512 threads x 5 quads (160 weight registers per thread, 256 VGPRs), 8-step phases.  Timeline per workgroup: weights
-// derived 10.8 us (the 53 MB guidance stream, HBM-bound), 3 x 7.4 us of steps (VALU-bound: ~270 instructions per
-// wavefront-step at 2 wavefronts per SIMD), 2 x (4 us exchange + 1.7 us halo staging), fused metrics ~7 us: 58 us per
-// scored forward against 73.5 us for the three S=8 launches, with 2.3x less HBM traffic.
+// 512 threads x 5 quads (160 weight registers per thread, 256 VGPRs, 2 wavefronts per SIMD), 8-step phases.  Timeline per
+// workgroup (tools/resident_stamps.py): weights derived 11.0 us (the guidance stream, HBM-bound) + 3.0 us until the
+// slowest wavefront has parked, 3 x 6.0 us of steps (VALU-bound: 228 instructions per wavefront-step, 160 of them FMAs),
+// 2 x (2.6 us exchange + 1.35 us halo staging), fused metrics + launch ~7 us: 48 us per scored forward against 73 us for
+// the three S=8 launches, with 2.3x less HBM traffic.
+//
+// What keeps the 256-VGPR instances spill-free (each item was a measured regression before it was written this way):
+//   * every scratch reload inside the derive is an s_waitcnt vmcnt(0) in the middle of the in-order guidance stream, so
+//     the derive carries nothing it does not need: loads / stores go through an SGPR base + 32-bit byte offset in address
+//     space 1 (at32: no address pairs, no flat loads), staging addresses advance without divisions, and everything the
+//     later stages address with is recomputed from late, opaque copies of the strip coordinates;
+//   * the step loop is unrolled by two with the LDS buffers RES_PP apart (the other buffer is an immediate offset, the
+//     carried quads alternate between two register sets instead of being copied), sits inside a wave-uniform branch,
+//     and computes unconditionally with masked stores;
+//   * v_pk_fma_f32 does not help: it issues at half the rate of v_fma_f32 here (tools/pk_fma_probe.hip).
 #include "cspn_common.hpp"
 
 #include <atomic>

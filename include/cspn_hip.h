@@ -236,7 +236,8 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * work: cspn3_resident_workspace_bytes(B,H,W) bytes, ZERO-initialised once by the caller, then only ever passed to this
  * entry.  seq: any value in [1, 2^31-256] that grows by at least 8 from one call on the same workspace to the next. */
 typedef struct cspn_resident_plan {
-    int steps_per_phase;   /* in: 0 = choose (8, stepping down to 4); out: the value used                  */
+    int steps_per_phase;   /* in: 0 = choose (8, 6 or 4); out: the value used.  Even whenever T needs more  */
+                           /* than one phase (an odd request then has no plan); any value <= T otherwise   */
     int tiles_x, tiles_y;  /* tiles per image                                                             */
     int tile_w, tile_h;
     int quads_per_thread, threads;

@@ -137,3 +137,29 @@ def test_batch_average_meter_reproduces_reference_averaging():
         assert np.isclose(avg[k], v, rtol=1e-6), k
     glob = ev.finalize_metrics(torch.from_numpy(total))
     assert not np.isclose(glob["rmse"], avg["rmse"], rtol=1e-4)   # the two conventions really differ
+
+
+def test_resident_plan_host_rules():
+    """Host-side tiling rules of the weight-resident launch (no GPU needed: cspn3_resident_plan is pure host code).
+    * a launch never has more workgroups than CUs, whole images per launch;
+    * phases have an even number of steps whenever there is more than one phase (every phase starts in LDS buffer 0,
+      the other buffer being a compile-time distance away), an odd request with several phases has no plan;
+    * one depth buffer fits the fixed slot (16352 floats) and the launch fits 160 KB of LDS."""
+    from cspn_monodepth_amd import functional as F
+    for (B, H, W) in ((24, 228, 304), (8, 352, 1216), (1, 352, 1216), (3, 228, 304), (5, 100, 64)):
+        for blend in (0, 1):
+            p = F.resident_plan(B, H, W, 24, blend, 256)
+            assert p is not None, (B, H, W)
+            assert p["tiles_x"] * p["tiles_y"] * p["images_per_launch"] <= 256
+            assert p["launches"] == -(-B // p["images_per_launch"])
+            assert p["steps_per_phase"] % 2 == 0 and p["lds_bytes"] <= 160 * 1024
+            hx = -(-(p["steps_per_phase"] - 1) // 4) * 4
+            dr, ls = p["tile_h"] + 2 * (p["steps_per_phase"] - 1) + 2, p["tile_w"] + 2 * hx + 8
+            assert dr * ls <= 16352, p
+            assert p["quads_per_thread"] <= 5 and p["threads"] == 512
+    assert F.resident_plan(24, 228, 304, 24, 0, 256)["steps_per_phase"] == 8            # the fitted cost model's choice
+    assert F.resident_plan(8, 352, 1216, 24, 0, 256)["steps_per_phase"] == 8
+    assert F.resident_plan(24, 228, 304, 24, 0, 256, steps_per_phase=5) is None         # 5 phases of 5 steps: odd
+    assert F.resident_plan(24, 228, 304, 5, 0, 256, steps_per_phase=5) is not None      # a single phase may be odd
+    assert F.resident_plan(24, 228, 304, 24, 0, 256, steps_per_phase=6)["steps_per_phase"] == 6
+    assert F.resident_plan(4, 64, 30, 24, 0, 256) is None                               # W % 4 != 0

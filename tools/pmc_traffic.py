@@ -34,7 +34,7 @@ for d in sorted(glob.glob(os.path.join(root, wl + "_*"))):
             res[sched][k]["_dispatches_" + c] = n
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cspn_monodepth_amd import _lib as _cl   # noqa: E402  (source digest only; nothing is launched)
-out = {"workload": wl, "per_kernel": res, "source_digest": _cl._source_digest([]),
+out = {"workload": wl, "per_kernel": res, "source_digest": _cl.code_digest(),
        "commit": os.environ.get("CSPN_COMMIT", "")}
 for sched in res:
     for k, v in res[sched].items():
