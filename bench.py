@@ -412,7 +412,7 @@ def main():
                               plan if K == 3 else F.dtype_default_plan(K, w_torch_dtype, plan))
     # which schedule will the step run?  (the weight-resident single launch serves the no-grad 3x3 calls it fits)
     res_plan = None
-    if K == 3 and B_local > 0 and args.graph != "on":       # (a captured step falls back to the multi-launch schedule)
+    if K == 3 and B_local > 0:                              # (also under --graph on: the capture records the launch + a flag memset)
         res_plan = F.resident_supported(g, d[:, 0], None if s is None else s[:, 0], T, plan,
                                         None if args.no_metrics else target[:, 0])
     if res_plan is not None:

@@ -580,8 +580,6 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
     """Can this no-grad 3x3 forward take the weight-resident launch?  (fp32, whole 16-byte quads, no explicit plan.)"""
     if _RESIDENT_MODE == "off" or plan is not None or _DEFAULT_PLANS.get(3) is not None or T < 1:
         return None
-    if torch.cuda.is_current_stream_capturing():
-        return None        # a HIP-graph replay would re-use the captured flag sequence number: the neighbour waits would not wait
     if guidance.dtype != torch.float32 or d0.dtype != torch.float32 or not from_guidance_supported(guidance, d0, sparse, None):
         return None
     if target is not None and (target.dtype != torch.float32 or target.data_ptr() % 16):
@@ -608,11 +606,26 @@ def check_resident_errors(dev=None):
 def _resident_launch(dev, B, H, W, T, launch):
     """The host protocol of every resident launch on `dev`: one at a time per device (lock; a launch from another stream
     first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence number,
-    the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call."""
+    the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call.
+
+    Under HIP-graph capture a replay cannot bring a new sequence number, so the capture records a memset of the
+    workspace's control words (status + tile flags, a few KB behind the two exchange planes: include/cspn_hip.h) in front
+    of the launch and uses a constant sequence number — every replay starts from zeroed flags.  The workspace comes from
+    the graph's private pool (it lives as long as the graph).  Replays are ordered by their stream like any launch; the
+    caller must not replay two graphs holding resident launches concurrently on one device (they could not both be
+    co-resident: the bounded wait would flag it)."""
     L = _lib.lib()
     log = _EVENT_LOG
     if log is not None and not log.take():
         log = None
+    if torch.cuda.is_current_stream_capturing():
+        nbytes = L.cspn3_resident_workspace_bytes(B, H, W)
+        work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        work[(2 * B * H * W * 4 + 15) & ~15:].zero_()
+        st = _resident_state(dev)
+        with _device_guard(dev):
+            cur = torch.cuda.current_stream(dev)
+            return launch(work, _RES_SEQ_STEP, st["host_err_ptr"], ctypes.c_void_p(cur.cuda_stream))
     with _RES_LOCK:
         st = _resident_state(dev)
         if st["host_err_np"][0] != 0:

@@ -234,7 +234,10 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * drains, and leaves `out` incomplete — the caller must check the word before trusting later results.
  *
  * work: cspn3_resident_workspace_bytes(B,H,W) bytes, ZERO-initialised once by the caller, then only ever passed to this
- * entry.  seq: any value in [1, 2^31-256] that grows by at least 8 from one call on the same workspace to the next. */
+ * entry.  seq: any value in [1, 2^31-256] that grows by at least 8 from one call on the same workspace to the next.
+ * Layout: the two exchange planes [2][B,H,W] f32 (never need initialising), rounded up to 16 bytes, then the control words
+ * (status + tile flags).  Re-zeroing the control words makes any seq valid again: a captured HIP graph records that memset
+ * in front of the launch and replays with a constant seq. */
 typedef struct cspn_resident_plan {
     int steps_per_phase;   /* in: 0 = choose (8, 6 or 4); out: the value used.  Even whenever T needs more  */
                            /* than one phase (an odd request then has no plan); any value <= T otherwise   */

@@ -190,20 +190,34 @@ def test_resident_does_not_depend_on_leftover_state(c_oracle):
     F.check_resident_errors()
 
 
-def test_resident_is_not_captured_into_hip_graphs(c_oracle):
-    """A captured resident launch would replay with a stale flag sequence number (its neighbour waits would not wait):
-    under stream capture the module must fall back to the multi-launch schedule, and the replay must stay correct."""
-    B, H, W, T = 3, 100, 148, 24
-    g, d, _ = c_oracle.synthetic_inputs(130, B, H, W, 12, None)
-    gt, dt = dev(g), dev(d)
+@pytest.mark.parametrize("B,H,W", [(3, 100, 148), (24, 228, 304), (8, 352, 1216)], ids=lambda v: str(v))
+def test_resident_launch_replays_from_a_hip_graph(B, H, W, c_oracle):
+    """A replay cannot bring a fresh flag sequence number: the capture records a memset of the workspace's control words in
+    front of the launch and a constant sequence number (functional._resident_launch).  Replays with NEW input values must
+    equal the eager results bit for bit — also when eager resident launches (their own, growing sequence numbers) run in
+    between, and for the two-launch plan of the KITTI batch; the scored variant accumulates the same sums."""
+    T = 24
     m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    ins = [c_oracle.synthetic_inputs(130 + k, B, H, W, 12, 300) for k in range(3)]
+    gt, dt, st = (dev(x).clone() for x in ins[0])
+    tgt = dev(np.maximum(ins[0][1] + 0.05, 0.0).astype(np.float32))
+    acc = pkg.evaluation.new_accumulator(DEV)
     with torch.no_grad(), resident("on"):
-        ref = m(gt, dt)
-        graphed = pkg.graphs.GraphedForward(lambda: m(gt, dt))
-        for _ in range(3):
-            out = graphed(copy_inputs=False)
+        assert F.resident_supported(gt, dt[:, 0], st[:, 0], T, None, tgt[:, 0]) is not None
+        graphed = pkg.graphs.GraphedForward(lambda: m.forward_scored(gt, dt, st, tgt, acc))
+        for k in (1, 2, 0, 1):
+            g, d, s = ins[k]
+            gt.copy_(dev(g)); dt.copy_(dev(d)); st.copy_(dev(s))
+            acc.zero_()
+            out = graphed(copy_inputs=False).clone()
+            got = acc.sum(0).cpu().numpy()
+            acc0 = pkg.evaluation.new_accumulator(DEV)
+            ref = m.forward_scored(gt, dt, st, tgt, acc0)                      # eager resident launch in between
+            assert torch.equal(out, ref), k
+            assert np.allclose(got, acc0.sum(0).cpu().numpy(), rtol=1e-6)
         torch.cuda.synchronize()
-    assert torch.equal(out, ref)
+    want = c_oracle.cspn3_forward(*ins[1], T)
+    assert rel_err(out.cpu().numpy(), want) <= 1e-5
     F.check_resident_errors()
 
 
