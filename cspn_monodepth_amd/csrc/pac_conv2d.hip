@@ -46,6 +46,33 @@ __device__ __forceinline__ int src_transposed(int o, int t, int S, int lead, int
     return v < N ? v : -1;
 }
 
+// Guarded scalar load: element `off` of `base` if ok, else 0.  A conditional load cannot be speculated, so it becomes an
+// exec-masked block of its own.  For fp32 that is fine — the masked load simply completes later, the wait sits at the
+// first use.  For fp16 the f16 -> f32 conversion sits INSIDE that block, right behind the load (the compiler sinks it
+// there: cvt(0) = 0): one serialised memory round trip per element — 11 per staged patch and thread, 4 per tap of the
+// transposed kernel, which is why the fp16 gradients ran at half the fp32 kernels' speed.  The tiled kernels therefore
+// load RAW bits under the mask (ld1_raw_or0) and convert where the value is consumed (raw_to_float: an empty asm keeps the
+// conversion from being sunk back), i.e. after every load of the batch has been issued.
+template <typename I>
+__device__ __forceinline__ float ld1_or0(const float* base, I off, bool ok) { return ok ? base[off] : 0.f; }
+template <typename I>
+__device__ __forceinline__ float ld1_or0(const __half* base, I off, bool ok) { return ok ? __half2float(base[off]) : 0.f; }
+template <typename I>
+__device__ __forceinline__ unsigned ld1_raw_or0(const float* base, I off, bool ok) { return ok ? __float_as_uint(base[off]) : 0u; }
+template <typename I>
+__device__ __forceinline__ unsigned ld1_raw_or0(const __half* base, I off, bool ok) {
+    return ok ? (unsigned)reinterpret_cast<const unsigned short*>(base)[off] : 0u;
+}
+template <typename T>
+__device__ __forceinline__ float raw_to_float(unsigned raw) {
+    if constexpr (std::is_same<T, __half>::value) {
+        asm("" : "+v"(raw));
+        return __half2float(__ushort_as_half((unsigned short)raw));
+    } else {
+        return __uint_as_float(raw);
+    }
+}
+
 template <typename T, bool VEC>
 __device__ __forceinline__ void load_quad(const T* p, int x0, int Wo, float (&v)[4]) {
     if constexpr (VEC) {
@@ -53,7 +80,7 @@ __device__ __forceinline__ void load_quad(const T* p, int x0, int Wo, float (&v)
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = x0 + e < Wo ? ld1(p + e) : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = ld1_or0(p, e, x0 + e < Wo);
     }
 }
 template <typename T, bool VEC>
@@ -113,7 +140,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd(const T* __restrict__ in, 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             // a zero of the padding still multiplies the kernel value (0 * inf = NaN, as F.unfold * kernel)
-                            const float v = xi[e] >= 0 ? ld1(row + xi[e]) : 0.f;
+                            const float v = ld1_or0(row, xi[e], xi[e] >= 0);
                             acc[cc][e] = fmaf(kv[e], v, acc[cc][e]);
                         }
                     }
@@ -154,7 +181,7 @@ struct TiledArgs {
 };
 
 template <typename T, int K, bool HOIST, int CB, bool TRANSPOSED>
-__global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
+__global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
                                                                          T* __restrict__ dst, TiledArgs a) {
     constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);     // LDS row pitch, a multiple of 4
     constexpr int RH = TILE_H + K - 1;
@@ -184,13 +211,13 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T
         const int yi = ty0 + a.org_y + ry, xi = tx0 + a.org_x + rx;
         goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.src_h && (unsigned)xi < (unsigned)a.src_w) ? yi * a.src_w + xi : -1;
     }
-    float pre[CB][NLD];
+    unsigned pre[CB][NLD];                              // raw bits: converted at commit time (see ld1_raw_or0)
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
             const T* sp = src + ((size_t)b * a.C + min(c0 + cc, a.C - 1)) * splane;
 #pragma unroll
-            for (int n = 0; n < NLD; ++n) pre[cc][n] = (c0 + cc < c_end && goff[n] >= 0) ? ld1(sp + goff[n]) : 0.f;
+            for (int n = 0; n < NLD; ++n) pre[cc][n] = ld1_raw_or0(sp, goff[n], c0 + cc < c_end && goff[n] >= 0);
         }
     };
     auto commit = [&](int buf) {
@@ -198,7 +225,7 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T
         for (int cc = 0; cc < CB; ++cc)
 #pragma unroll
             for (int n = 0; n < NLD; ++n)
-                if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = pre[cc][n];
+                if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = raw_to_float<T>(pre[cc][n]);
     };
     float kr[KR][4];
     // taps [first, first+n) in window order (row-major over (i',j')) of kernel channel kc -> kr[0..n)
@@ -216,13 +243,19 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T
             for (int t = 0; t < n; ++t) {
                 const int w = first + t, wi = w / K, wj = w - wi * K;      // window position (i',j'); constants after unrolling
                 const int sy = y + a.org_y + wi;
-                const T* kp = kb + (size_t)(K * K - 1 - w) * kplane + (size_t)sy * a.k_w;   // flipped tap, source row
                 const bool rowok = (unsigned)sy < (unsigned)a.k_h;
+                const T* kp = kb + (size_t)(K * K - 1 - w) * kplane + (size_t)(rowok ? sy : 0) * a.k_w;   // flipped tap, (safe) source row
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int sx = x0 + e + a.org_x + wj;
-                    kr[t][e] = (rowok && (unsigned)sx < (unsigned)a.k_w) ? ld1(kp + sx) : 0.f;
+                    kr[t][e] = __uint_as_float(ld1_raw_or0(kp, sx, rowok && (unsigned)sx < (unsigned)a.k_w));
                 }
+            }
+            if constexpr (std::is_same<T, __half>::value) {        // all n taps are in flight: now the raw halfs become floats
+#pragma unroll
+                for (int t = 0; t < n; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kr[t][e] = raw_to_float<T>(__float_as_uint(kr[t][e]));
             }
         }
     };
@@ -299,6 +332,128 @@ __global__ __launch_bounds__(256, (K > 5 ? 3 : 1)) void pac_conv2d_tiled(const T
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, tiled, fp16 octs
+// The fp16 form of pac_conv2d_tiled (forward, K <= 5): in fp16 the quad kernel moves its taps as 8-byte loads and runs at
+// the fp32 kernel's instruction rate, i.e. at half its byte rate (30 % of the HBM peak).  Here a thread owns EIGHT
+// consecutive output pixels: every tap plane is one 16-byte load per thread, the taps stay packed (two halfs per VGPR:
+// K*K*4 registers, as many as the fp32 quad kernel uses for half the pixels) and feed v_fma_mix_f32 directly (f16 tap
+// x f32 window value + f32 accumulator: the same arithmetic as converting the tap first), the eight results leave as
+// one 16-byte store.  Tile 128 x 16 per workgroup, channels double-buffered through LDS exactly like pac_conv2d_tiled.
+__device__ __forceinline__ float fma_h8(const uint4& r, int e, float x, float acc) {
+    const unsigned w = (e >> 1) == 0 ? r.x : ((e >> 1) == 1 ? r.y : ((e >> 1) == 2 ? r.z : r.w));
+    float out;
+    if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
+    return out;
+}
+
+constexpr int TILE_W8 = 128;
+
+// HOIST (shared kernel, several channels): all K*K taps are loaded once and stay in registers for every channel.
+// Otherwise: one tap ROW at a time, double-buffered (row i+1 is requested before row i is applied; row 0 before the
+// source patch is staged) — 8 K tap registers instead of 4 K*K, so that five wavefronts per SIMD are resident and a
+// single-channel launch (the CSPN_ours step: a pure stream) fits the chip in one round.
+template <int K, bool HOIST>
+__global__ __launch_bounds__(256, (HOIST ? 1 : 4)) void pac_conv2d_tiled_h8(const __half* __restrict__ src, const __half* __restrict__ kern,
+                                                           __half* __restrict__ dst, TiledArgs a) {
+    constexpr int RW = TILE_W8 + ((K - 1 + 3) & ~3);
+    constexpr int RH = TILE_H + K - 1;
+    constexpr int PATCH = RH * RW;
+    constexpr int NLD = (PATCH + 255) / 256;
+    constexpr int NQUAD = (K + 7 + 3) / 4;              // aligned quads covering the K+7 window columns
+    __shared__ __attribute__((aligned(16))) float tile[2][PATCH];
+    const int tid = blockIdx.x;
+    const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
+    const int tx0 = tx * TILE_W8, ty0 = ty * TILE_H;
+    const int ox = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x0 = tx0 + 8 * ox, y = ty0 + ly;
+    const bool live = y < a.dst_h && x0 < a.dst_w;      // dst_w % 8 == 0 (launcher): an oct is inside or outside as a whole
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t kplane = (size_t)a.k_h * a.k_w, splane = (size_t)a.src_h * a.src_w, dplane = (size_t)a.dst_h * a.dst_w;
+    const size_t dpix = (size_t)y * a.dst_w + x0;
+
+    // patch element -> offset in the source plane, -1 = zero.  Kept in registers across the channels only by the HOIST
+    // instance; the row-wise instance recomputes it per fetch (it lives on occupancy: 11 registers matter)
+    auto patch_off = [&](int n) -> int {
+        const int idx = threadIdx.x + 256 * n;
+        const int ry = idx / RW, rx = idx - ry * RW;
+        const int yi = ty0 + a.org_y + ry, xi = tx0 + a.org_x + rx;
+        return (idx < PATCH && (unsigned)yi < (unsigned)a.src_h && (unsigned)xi < (unsigned)a.src_w) ? yi * a.src_w + xi : -1;
+    };
+    int goff[HOIST ? NLD : 1];
+    if (HOIST) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) goff[HOIST ? n : 0] = patch_off(n);
+    }
+    unsigned pre[NLD];                                  // raw halfs: converted at commit time (see ld1_raw_or0)
+    auto fetch = [&](int c) {
+        const __half* sp = src + ((size_t)b * a.C + min(c, a.C - 1)) * splane;
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int o = HOIST ? goff[HOIST ? n : 0] : patch_off(n);
+            pre[n] = ld1_raw_or0(sp, o, c < c_end && o >= 0);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n)
+            if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][threadIdx.x + 256 * n] = raw_to_float<__half>(pre[n]);
+    };
+    constexpr int KR = HOIST ? K * K : 2 * K;
+    uint4 kr[KR];
+    auto load_taps = [&](int kc, int first, int n, int at) {   // taps [first, first + n) of kernel channel kc -> kr[at ..]
+        const __half* kp = kern + (((size_t)b * a.CK + kc) * (K * K) + first) * kplane + dpix;
+#pragma unroll
+        for (int t = 0; t < n; ++t) kr[at + t] = *reinterpret_cast<const uint4*>(kp + (size_t)t * kplane);
+    };
+
+    if (live) {
+        if (HOIST) load_taps(0, 0, K * K, 0);
+        else load_taps(a.CK == 1 ? 0 : c_begin, 0, K, 0);
+    }
+    fetch(c_begin);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = c + 1 < c_end;
+        if (more) fetch(c + 1);
+        if (live) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (!HOIST) {
+                    if (i + 1 < K) load_taps(a.CK == 1 ? 0 : c, (i + 1) * K, K, ((i + 1) & 1) * K);
+                    else if (more) load_taps(a.CK == 1 ? 0 : c + 1, 0, K, ((i + 1) & 1) * K);   // K odd: row 0 of the next channel lands in half 0
+                }
+                float win[4 * NQUAD];
+#pragma unroll
+                for (int n = 0; n < NQUAD; ++n) {
+                    const v4f v = *(lds_cv4f_ptr)(&tile[buf][(ly + i) * RW + 8 * ox + 4 * n]);
+                    win[4 * n] = v.x; win[4 * n + 1] = v.y; win[4 * n + 2] = v.z; win[4 * n + 3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fma_h8(kr[HOIST ? i * K + j : (i & 1) * K + j], e, win[j + e], acc[e]);
+                if (!HOIST) __builtin_amdgcn_sched_barrier(0);   // one row of taps ahead, not all of them (registers = occupancy)
+            }
+            uint4 o;
+            *reinterpret_cast<__half2*>(&o.x) = __floats2half2_rn(acc[0], acc[1]);
+            *reinterpret_cast<__half2*>(&o.y) = __floats2half2_rn(acc[2], acc[3]);
+            *reinterpret_cast<__half2*>(&o.z) = __floats2half2_rn(acc[4], acc[5]);
+            *reinterpret_cast<__half2*>(&o.w) = __floats2half2_rn(acc[6], acc[7]);
+            *reinterpret_cast<uint4*>(dst + ((size_t)b * a.C + c) * dplane + dpix) = o;
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward, tiled, any geometry
 // Strided / dilated / non-square windows: same 64 x 16 output tile, the input patch it touches —
 // ((64-1) sw + (kw-1) dw + 1) x ((16-1) sh + (kh-1) dh + 1) — staged in dynamic LDS for `cb` channels at a time and the
@@ -343,7 +498,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restr
                 const bool ok = (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
                 const size_t goff = (size_t)(ok ? yi : 0) * a.W + (ok ? xi : 0);
                 for (int cc = 0; cc < nc; ++cc)
-                    patch[cc * psz + idx] = ok ? ld1(in + ((size_t)b * a.C + c + cc) * iplane + goff) : 0.f;
+                    patch[cc * psz + idx] = ld1_or0(in + ((size_t)b * a.C + c + cc) * iplane, goff, ok);
                 rx += step_rx; ry += step_ry;
                 if (rx >= RW) { rx -= RW; ++ry; }
             }
@@ -364,7 +519,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restr
             if constexpr (SHARED) {
                 const T* kp = kern + ((size_t)b * ntap + tap) * oplane;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) kv[e] = live[e] ? ld1(kp + opix[e]) : 0.f;
+                for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, opix[e], live[e]);
             }
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
@@ -372,7 +527,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restr
                     if constexpr (!SHARED) {
                         const T* kp = kern + (((size_t)b * a.C + c + cc) * ntap + tap) * oplane;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) kv[e] = live[e] ? ld1(kp + opix[e]) : 0.f;
+                        for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, opix[e], live[e]);
                     }
                     const float* pp = patch + cc * psz + base;
 #pragma unroll
@@ -419,7 +574,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk(const T* __restrict__ gout,
         const T* row = in + ((size_t)b * a.C + c) * iplane + (size_t)(yi < 0 ? 0 : yi) * a.W;
         float p[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p[e] = g[e] * (xi[e] >= 0 ? ld1(row + xi[e]) : 0.f);
+        for (int e = 0; e < 4; ++e) p[e] = g[e] * ld1_or0(row, xi[e], xi[e] >= 0);
         if constexpr (SHARED) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += p[e];
@@ -470,8 +625,8 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk_tiled(const T* __restrict__
             const int cc = idx / (TILE_H * RW), r = idx - cc * (TILE_H * RW);
             const int ry = r / RW, rx = r - ry * RW;
             const int yi = ty0 - a.ph + i + ry, xi = tx0 - a.pw + rx;
-            tile[cc][r] = ((unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
-                              ? ld1(in + ((size_t)b * a.C + c + cc) * iplane + (size_t)yi * a.W + xi) : 0.f;
+            tile[cc][r] = ld1_or0(in + ((size_t)b * a.C + c + cc) * iplane, (size_t)yi * a.W + xi,
+                                  (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W);
         }
         __syncthreads();
         if (live) {
@@ -546,14 +701,15 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk_window(const T* __restrict_
         const int yi = ty0 + a.org_y + ry, xi = tx0 + a.org_x + rx;
         goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.src_h && (unsigned)xi < (unsigned)a.src_w) ? yi * a.src_w + xi : -1;
     }
-    float pre[CB][NLD], gpre[CB][4], g[CB][4];
+    unsigned pre[CB][NLD];                              // raw bits: converted at commit time (see ld1_raw_or0)
+    float gpre[CB][4], g[CB][4];
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
             const int c = min(c0 + cc, a.C - 1);
             const T* sp = in + ((size_t)b * a.C + c) * splane;
 #pragma unroll
-            for (int n = 0; n < NLD; ++n) pre[cc][n] = (c0 + cc < c_end && goff[n] >= 0) ? ld1(sp + goff[n]) : 0.f;
+            for (int n = 0; n < NLD; ++n) pre[cc][n] = ld1_raw_or0(sp, goff[n], c0 + cc < c_end && goff[n] >= 0);
             if (live && c0 + cc < c_end) {
                 const T* gp = gout + ((size_t)b * a.C + c) * dplane + dpix;
                 if (a.dst_vec) load_quad<T, true>(gp, x0, a.dst_w, gpre[cc]);
@@ -566,7 +722,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk_window(const T* __restrict_
         for (int cc = 0; cc < CB; ++cc) {
 #pragma unroll
             for (int n = 0; n < NLD; ++n)
-                if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = pre[cc][n];
+                if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][cc][threadIdx.x + 256 * n] = raw_to_float<T>(pre[cc][n]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[cc][e] = gpre[cc][e];
         }
@@ -678,7 +834,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_gi(const T* __restrict__ gout,
                 if constexpr (SHARED) {
                     const T* kp = kern + ((size_t)b * ntap + tap) * oplane + orow;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) kv[e] = xo[e] >= 0 ? ld1(kp + xo[e]) : 0.f;
+                    for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, xo[e], xo[e] >= 0);
                 }
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc) {
@@ -686,7 +842,7 @@ __global__ __launch_bounds__(256) void pac_conv2d_gi(const T* __restrict__ gout,
                         if constexpr (!SHARED) {
                             const T* kp = kern + (((size_t)b * a.C + c + cc) * ntap + tap) * oplane + orow;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) kv[e] = xo[e] >= 0 ? ld1(kp + xo[e]) : 0.f;
+                            for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, xo[e], xo[e] >= 0);
                         }
                         const T* gp = gout + ((size_t)b * a.C + c + cc) * oplane + orow;
 #pragma unroll
@@ -723,7 +879,7 @@ __global__ __launch_bounds__(256) void pac_nd2col_kernel(const T* __restrict__ i
     for (int e = 0; e < 4; ++e) {
         const int xi = a.transposed ? src_transposed(x0 + e, j, a.sw, a.lead_w, a.dw, a.W)
                                     : src_plain(x0 + e, j, a.sw, a.pw, a.dw, a.W);
-        v[e] = (yi >= 0 && xi >= 0 && x0 + e < a.Wo) ? ld1(in + (size_t)bc * iplane + (size_t)yi * a.W + xi) : 0.f;
+        v[e] = ld1_or0(in + (size_t)bc * iplane, (size_t)yi * a.W + xi, yi >= 0 && xi >= 0 && x0 + e < a.Wo);
     }
     store_quad<T, VEC>(cols + ((size_t)bc * (a.kh * a.kw) + tap) * oplane + (size_t)y * a.Wo + x0, x0, a.Wo, v);
 }
@@ -812,6 +968,22 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
         t.org_y = -a.ph; t.org_x = -a.pw;
     }
     t.k_vec = a.vec; t.dst_vec = dst_vec;
+    if constexpr (std::is_same<T, __half>::value && !TRANSPOSED && K <= 5) {
+        // fp16 forward with whole 16-byte octs everywhere: the eight-pixel kernel (2x the bytes per load instruction)
+        if (a.vec && dst_vec && t.dst_w % 8 == 0 && ((reinterpret_cast<uintptr_t>(kern) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+            t.tiles_x = ceil_div(t.dst_w, TILE_W8);
+            const int tiles8 = t.tiles_x * ceil_div(t.dst_h, TILE_H);
+            const size_t want8 = 1024, have8 = (size_t)tiles8 * a.B;
+            int nchunk8 = (int)std::min<size_t>((want8 + have8 - 1) / have8, (size_t)a.C);
+            if (a.CK != 1) nchunk8 = (int)std::min<size_t>((4 * want8 + have8 - 1) / have8, (size_t)a.C);
+            t.cchunk = ceil_div(a.C, std::max(nchunk8, 1));
+            const dim3 grid8(tiles8, ceil_div(a.C, t.cchunk), a.B), block8(256);
+            if (a.CK == 1 && t.cchunk > 1) pac_conv2d_tiled_h8<K, true><<<grid8, block8, 0, st>>>(src, kern, dst, t);
+            else pac_conv2d_tiled_h8<K, false><<<grid8, block8, 0, st>>>(src, kern, dst, t);
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     t.tiles_x = ceil_div(t.dst_w, TILE_W);
     const int tiles = t.tiles_x * ceil_div(t.dst_h, TILE_H);
     // every channel chunk re-reads the kernel planes, so only split as far as filling the chip needs (~4 x 256 groups)
