@@ -669,6 +669,96 @@ __global__ __launch_bounds__(256) void pac_conv2d_gk_tiled(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dL/dkernel, fp16 octs
+// dL/dkernel without a sum over channels (one kernel per channel, or a single channel: what a CSPN_ours step has) is an
+// outer product  grad_kernel[c,i,j][q] = grad_out[c][q] * in[c][q + (i,j)]  — 2 + 2 bytes read and 2 K*K written per pixel,
+// a pure store stream.  The fp16 quad kernel writes it as 8-byte stores (half the bytes per instruction); here a thread
+// owns eight pixels: one 16-byte load of grad_out, window rows from the LDS patch, K*K 16-byte stores.
+template <int K>
+__global__ __launch_bounds__(256) void pac_conv2d_gk_h8(const __half* __restrict__ gout, const __half* __restrict__ in,
+                                                        __half* __restrict__ gk, TiledArgs a) {
+    constexpr int RW = TILE_W8 + ((K - 1 + 3) & ~3);
+    constexpr int RH = TILE_H + K - 1;
+    constexpr int PATCH = RH * RW;
+    constexpr int NLD = (PATCH + 255) / 256;
+    constexpr int NQUAD = (K + 7 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[2][PATCH];
+    const int tid = blockIdx.x;
+    const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
+    const int tx0 = tx * TILE_W8, ty0 = ty * TILE_H;
+    const int ox = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x0 = tx0 + 8 * ox, y = ty0 + ly;
+    const bool live = y < a.dst_h && x0 < a.dst_w;      // dst_w % 8 == 0 (launcher)
+    const int b = blockIdx.z;
+    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const size_t splane = (size_t)a.src_h * a.src_w, dplane = (size_t)a.dst_h * a.dst_w;
+    const size_t dpix = (size_t)y * a.dst_w + x0;
+
+    int goff[NLD];
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int idx = threadIdx.x + 256 * n;
+        const int ry = idx / RW, rx = idx - ry * RW;
+        const int yi = ty0 + a.org_y + ry, xi = tx0 + a.org_x + rx;
+        goff[n] = (idx < PATCH && (unsigned)yi < (unsigned)a.src_h && (unsigned)xi < (unsigned)a.src_w) ? yi * a.src_w + xi : -1;
+    }
+    unsigned pre[NLD];
+    uint4 gpre = make_uint4(0u, 0u, 0u, 0u), graw = gpre;
+    auto fetch = [&](int c) {
+        const __half* sp = in + ((size_t)b * a.C + min(c, a.C - 1)) * splane;
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) pre[n] = ld1_raw_or0(sp, goff[n], c < c_end && goff[n] >= 0);
+        if (live && c < c_end) gpre = *reinterpret_cast<const uint4*>(gout + ((size_t)b * a.C + c) * dplane + dpix);
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n)
+            if (256 * (n + 1) <= PATCH || threadIdx.x + 256 * n < PATCH) tile[buf][threadIdx.x + 256 * n] = raw_to_float<__half>(pre[n]);
+        graw = gpre;
+    };
+    fetch(c_begin);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = c + 1 < c_end;
+        const uint4 gc = graw;                              // this channel's grad_out oct (commit below overwrites graw)
+        if (more) fetch(c + 1);
+        if (live) {
+            float g[8];
+            {
+                const float2 a0 = __half22float2(*reinterpret_cast<const __half2*>(&gc.x));
+                const float2 a1 = __half22float2(*reinterpret_cast<const __half2*>(&gc.y));
+                const float2 a2 = __half22float2(*reinterpret_cast<const __half2*>(&gc.z));
+                const float2 a3 = __half22float2(*reinterpret_cast<const __half2*>(&gc.w));
+                g[0] = a0.x; g[1] = a0.y; g[2] = a1.x; g[3] = a1.y; g[4] = a2.x; g[5] = a2.y; g[6] = a3.x; g[7] = a3.y;
+            }
+            __half* dp = gk + ((size_t)b * a.C + c) * (K * K) * dplane + dpix;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float win[4 * NQUAD];
+#pragma unroll
+                for (int n = 0; n < NQUAD; ++n) {
+                    const v4f v = *(lds_cv4f_ptr)(&tile[buf][(ly + i) * RW + 8 * ox + 4 * n]);
+                    win[4 * n] = v.x; win[4 * n + 1] = v.y; win[4 * n + 2] = v.z; win[4 * n + 3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    uint4 o;
+                    *reinterpret_cast<__half2*>(&o.x) = __floats2half2_rn(g[0] * win[j], g[1] * win[j + 1]);
+                    *reinterpret_cast<__half2*>(&o.y) = __floats2half2_rn(g[2] * win[j + 2], g[3] * win[j + 3]);
+                    *reinterpret_cast<__half2*>(&o.z) = __floats2half2_rn(g[4] * win[j + 4], g[5] * win[j + 5]);
+                    *reinterpret_cast<__half2*>(&o.w) = __floats2half2_rn(g[6] * win[j + 6], g[7] * win[j + 7]);
+                    *reinterpret_cast<uint4*>(dp + (size_t)(i * K + j) * dplane) = o;
+                }
+            }
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dL/dkernel, whole window
 // K <= 5: one workgroup produces all K*K kernel-gradient planes of its tile in one pass — the input patches and the
 // grad_out quads of the next channel batch are prefetched exactly as in pac_conv2d_tiled; with a shared kernel the
@@ -1060,6 +1150,25 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
 template <typename T, int K>
 int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
     const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+    if constexpr (std::is_same<T, __half>::value && K <= 5) {
+        // fp16, no sum over channels (CK == C), whole 16-byte octs: the eight-pixel outer-product kernel
+        if (a.CK == a.C && a.vec && a.Wo % 8 == 0 &&
+            ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gk)) & 15) == 0) {
+            TiledArgs t{};
+            t.B = a.B; t.C = a.C; t.CK = a.CK;
+            t.src_h = a.H; t.src_w = a.W; t.dst_h = a.Ho; t.dst_w = a.Wo; t.k_h = a.Ho; t.k_w = a.Wo;
+            t.org_y = -a.ph; t.org_x = -a.pw;
+            t.k_vec = t.dst_vec = a.vec;
+            t.tiles_x = ceil_div(a.Wo, TILE_W8);
+            const int tiles8 = t.tiles_x * ceil_div(a.Ho, TILE_H);
+            const int nchunk = (int)std::min<size_t>((4096 + (size_t)tiles8 * a.B - 1) / ((size_t)tiles8 * a.B), (size_t)a.C);
+            t.cchunk = ceil_div(a.C, std::max(nchunk, 1));
+            const dim3 grid8(tiles8, ceil_div(a.C, t.cchunk), a.B), block8(256);
+            pac_conv2d_gk_h8<K><<<grid8, block8, 0, st>>>(g, in, gk, t);
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     if constexpr (K <= 5) {
         // whole-window kernel; a shared kernel pins all channels to one workgroup, so it needs enough tiles to fill the
         // chip — small launches keep the tap-row split below (K x the workgroups)
