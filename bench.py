@@ -235,6 +235,9 @@ def run_train(args, wl, world, rank, local_rank, device):
     from cspn_monodepth_amd.network import unet_cspn_nyu
     import torch.nn as nn
     B, H, W = wl["B"], wl["H"], wl["W"]
+    # the reference's trainer sets cudnn.benchmark (main.py:37): MIOpen then picks every convolution algorithm by timing —
+    # 36.5 -> 28.3 ms per step here, but ~8 minutes of searching on a fresh box (no tuning database travels), hence opt-in
+    torch.backends.cudnn.benchmark = (args.conv_autotune == "on")
     torch.manual_seed(0)
     model = unet_cspn_nyu.resnet50(reference_state_dict=False, cspn_plan=parse_plan(args.plan)).to(device)
     if world > 1:
@@ -311,6 +314,7 @@ def run_train(args, wl, world, rank, local_rank, device):
                "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
                           "prop_time": wl["T"], "optimizer": "SGD(momentum 0.9, wd 1e-4)", "loss": "MaskedL1",
                           "parameters": int(sum(p.numel() for p in model.parameters())),
+                          "conv_autotune": args.conv_autotune,
                           "parallelism": "DDP x%d over RCCL + SyncBatchNorm" % world if world > 1 else "single GPU"},
                "roofline": None,
                "cspn_module": {"forward_us_p50": med(fwd_us), "backward_us_p50": med(bwd_us),
@@ -344,6 +348,9 @@ def main():
     ap.add_argument("--cold-sets", type=int, default=8,
                     help="extra leg: rotate over this many input sets (SURVEY.md 8d: >= 8 sets, > 256 MiB in total); 0/1 disables it")
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed steady-state pre-warm-up before the W warm-up steps")
+    ap.add_argument("--conv-autotune", choices=("on", "off"), default="off",
+                    help="--workload train: torch.backends.cudnn.benchmark (MIOpen find mode) as the reference's main.py:37; "
+                         "slow first steps (minutes)")
     ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
     args = ap.parse_args()
 
