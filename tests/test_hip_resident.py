@@ -46,7 +46,8 @@ def both(g, d, s, T):
 
 
 SHAPES = [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (8, 352, 1216, 24), (1, 228, 304, 24), (2, 13, 20, 24),
-          (5, 60, 64, 7), (2, 37, 8, 1), (1, 1, 12, 3), (3, 100, 148, 9), (1, 5, 4, 6), (30, 120, 160, 17)]
+          (5, 60, 64, 7), (2, 37, 8, 1), (1, 1, 12, 3), (3, 100, 148, 9), (1, 5, 4, 6), (30, 120, 160, 17),
+          (97, 228, 304, 24)]           # five resident launches per call (the auto policy has no cap on their number)
 
 
 @pytest.mark.parametrize("B,H,W,T", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
