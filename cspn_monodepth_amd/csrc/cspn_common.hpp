@@ -102,27 +102,35 @@ __device__ __forceinline__ void div8_shared_reciprocal(const float (&a)[8], floa
 // The 10 masked terms of Result.evaluate (libs/metrics.py:49-83) for one pixel, added to f[0..9]:
 // {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), 1} over t > 0.
 // Algebraically equal forms that avoid cancellation and redundant divisions:
-//   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)|,
-//   max(o/t, t/o) < c  <=>  o < c t  and  (o > 0 ? t < c o : o < 0)      (t > 0; NaN -> false as torch.max)
+//   |1/o - 1/t| = |o-t| / |o t|,   |log10 o - log10 t| = |log10(o/t)| = |log2(o/t)| log10(2),
+//   max(o/t, t/o) < c  <=>  |log2(o/t)| < log2(c)  for o > 0;  o < 0 counts (both ratios are negative), o = 0 and NaN do not
+//   (torch.max semantics) — the one logarithm of the log-error term serves the three thresholds.
 // Reciprocals and the logarithm use the hardware v_rcp_f32 / v_log_f32 (1 ulp): the terms are summed over
 // ~10^5..10^6 pixels and compared at 1e-5, and IEEE divisions + log10f made this reduction VALU-bound.
+// Branch- and select-free masking: an invalid pixel (t <= 0 or NaN) is scored as o = t = 1, which adds exactly 0 to the six
+// error sums, and the four counters take the validity as a condition.  ~30 VALU operations + 3 transcendentals per pixel;
+// the form with six products and twelve compares per pixel (86 instructions with its masking) was 5.7 us of every scored
+// config-2 forward.
 __device__ __forceinline__ void metric_terms(float o, float t, float (&f)[10]) {
-    if (!(t > 0.f)) return;
-    const float ad = fabsf(o - t);
-    const float rt = __builtin_amdgcn_rcpf(t);
-    const float inv = ad * __builtin_amdgcn_rcpf(fabsf(o * t));
+    const bool valid = t > 0.f;
+    const float tt = valid ? t : 1.f, oo = valid ? o : 1.f;
+    const float ad = fabsf(oo - tt);
+    const float rt = __builtin_amdgcn_rcpf(tt);
+    const float inv = ad * __builtin_amdgcn_rcpf(fabsf(oo * tt));
     f[0] = fmaf(inv, inv, f[0]);
     f[1] += inv;
     f[2] = fmaf(ad, ad, f[2]);
     f[3] += ad;
     f[4] = fmaf(ad, rt, f[4]);
-    f[5] += fabsf(__builtin_amdgcn_logf(o * rt)) * 0.30102999566398120f;     // |log10(o/t)| = |log2(o/t)| log10(2)
-    const float c1 = 1.25f, c2 = 1.25f * 1.25f, c3 = 1.25f * 1.25f * 1.25f;
-    const bool pos = o > 0.f, neg = o < 0.f;
-    f[6] += (o < c1 * t && (pos ? t < c1 * o : neg)) ? 1.f : 0.f;
-    f[7] += (o < c2 * t && (pos ? t < c2 * o : neg)) ? 1.f : 0.f;
-    f[8] += (o < c3 * t && (pos ? t < c3 * o : neg)) ? 1.f : 0.f;
-    f[9] += 1.f;
+    const float r = oo * rt;
+    const float lg = fabsf(__builtin_amdgcn_logf(r));                       // |log2(o/t)|; NaN for o < 0 (as log10 of a negative)
+    f[5] = fmaf(lg, 0.30102999566398120f, f[5]);
+    const bool neg = r < 0.f;
+    constexpr float L1 = 0.32192809488736235f;                             // log2(1.25)
+    f[6] += (valid && (lg < L1 || neg)) ? 1.f : 0.f;
+    f[7] += (valid && (lg < 2.f * L1 || neg)) ? 1.f : 0.f;
+    f[8] += (valid && (lg < 3.f * L1 || neg)) ? 1.f : 0.f;
+    f[9] += valid ? 1.f : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
