@@ -216,7 +216,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     unsigned in_img = 0, interior = 0;
     float* const md_lds = lds + RES_PP + (size_t)a.dr * a.ls;     // private slots: m * d0 of the owned quads
     const float* __restrict__ gq = uniform_ptr(a.g + (size_t)b * a.g_bs);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j: the aligned quad of row y+dy gives three of
     // the four shifted values, the fourth is the neighbouring lane's quad (DPP) or, at strip ends / wave edges, a scalar.
     // All loads are branch-free (safe address + select: a conditional load becomes its own basic block with its own wait)
@@ -298,7 +297,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        const int r = r0 + i;
         const bool ok = (in_img >> i) & 1u;
         // does edge[i][t] hold a pixel inside the image?  (recomputed: a bit mask built while the loads are issued is one
         // more live register there)
