@@ -22,7 +22,7 @@
 // 512 threads x 5 quads (160 weight registers per thread, 256 VGPRs, 2 wavefronts per SIMD), 8-step phases.  Timeline per
 // workgroup (tools/resident_stamps.py): weights derived 11.0 us (the guidance stream, HBM-bound) + 3.0 us until the
 // slowest wavefront has parked, 3 x 6.0 us of steps (VALU-bound: 228 instructions per wavefront-step, 160 of them FMAs),
-// 2 x (2.6 us exchange + 1.35 us halo staging), fused metrics + launch ~7 us: 48 us per scored forward against 73 us for
+// 2 x (2.6 us exchange + 1.35 us halo staging), fused metrics 3.6 us + launch ~2 us: 46 us per scored forward against 73 us for
 // the three S=8 launches, with 2.3x less HBM traffic.
 //
 // What keeps the 256-VGPR instances spill-free (each item was a measured regression before it was written this way):
