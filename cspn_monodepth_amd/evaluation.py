@@ -116,7 +116,8 @@ def all_gather_metric_sums(sums, group=None):
     if sums.dim() == 2:
         sums = sums.sum(0)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return sums.clone(), sums.unsqueeze(0).clone()
+        total = sums.clone()                              # one rank: nothing to gather (the per-rank view shares `total`)
+        return total, total.unsqueeze(0)
     world = dist.get_world_size(group)
     src = sums.contiguous()
     if sums.is_cuda and dist.get_backend(group) == "gloo":
