@@ -306,3 +306,31 @@ def test_native_impl_formulation_backpropagates_through_nd2col():
     for got, key in ((x.grad, "grad_input_f64"), (kern.grad, "grad_kernel_f64")):
         want = z[key]
         assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("K", [3, 5])
+@pytest.mark.parametrize("C,CK", [(1, 1), (3, 1), (3, 3)])
+@pytest.mark.parametrize("Ho,Wo,same", [(19, 136, True), (33, 304, True), (5, 8, True), (21, 264, False)])
+def test_fp16_eight_pixel_kernels(K, C, CK, Ho, Wo, same):
+    """fp16 with whole 16-byte octs (Wo % 8 == 0) takes pac_conv2d_tiled_h8 for the forward and, without a channel sum
+    (CK == C), pac_conv2d_gk_h8 for dL/dkernel; the input gradient loads its guarded halfs raw and converts late.  Several
+    128 x 16 tiles with ragged last rows / columns, 'same' and no padding, against the oracle on the fp16-rounded inputs and
+    against the generic kernels."""
+    rng = np.random.default_rng(7000 + 100 * K + 10 * C + CK + Ho + Wo)
+    p = (K // 2, K // 2) if same else (0, 0)
+    H, W = Ho + K - 1 - 2 * p[0], Wo + K - 1 - 2 * p[1]
+    B = 2
+    x = rng.standard_normal((B, C, H, W)).astype(np.float16).astype(np.float32)
+    kern = (rng.standard_normal((B, CK, K, K, Ho, Wo)) * 0.3).astype(np.float16).astype(np.float32)
+    cot = rng.standard_normal((B, C, Ho, Wo)).astype(np.float16).astype(np.float32)
+    assert porc.out_size((H, W), K, 1, p, 1) == (Ho, Wo)
+    want = porc.pac_conv2d_forward(x, kern, K, 1, p, 1, dtype=np.float64)
+    wgi, wgk = porc.pac_conv2d_backward(x, kern, cot, K, 1, p, 1)
+    res = {}
+    for scalar in (0, 1):
+        with force_generic(scalar):
+            res[scalar] = run_all(x, kern, cot, K, 1, p, 1, torch.float16)
+        out, gi, gk = res[scalar]
+        assert nmax(out, want) <= 2e-3 and nmax(gi, wgi) <= 2e-3 and nmax(gk, wgk) <= 2e-3, (scalar, nmax(out, want), nmax(gi, wgi), nmax(gk, wgk))
+    # same fp32 accumulation order per output in both forward kernels and an exact product in dL/dkernel: identical halfs
+    assert np.array_equal(res[0][2], res[1][2])
