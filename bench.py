@@ -75,13 +75,13 @@ def make_inputs(wl, B, device, seed, sparse):
     return g, d, s, target
 
 
-def load_pmc_traffic(tag, schedule="fused"):
+def load_pmc_traffic(tag, schedule="fused", launches_of_rarest=1):
     """HBM traffic per launch from the committed rocprofv3 --pmc summary of this workload (profiles/*_pmc_traffic_<tag>
     .json, newest round first).  `schedule`: "fused" = the passes of the default schedule (the weight-resident launch
     where it applies), "multi" = the passes with CSPN_RESIDENT=off.  `stale` = the kernel sources changed since."""
     import glob
     out = {"source": None, "stale": None, "step_bytes_per_launch": None, "fused_bytes_per_forward": None,
-           "fused_per_launch": None, "sq": None}
+           "fused_per_launch": None, "per_kernel_per_forward": None, "sq": None}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % tag)), reverse=True)
     if not files:
         return out
@@ -97,11 +97,17 @@ def load_pmc_traffic(tag, schedule="fused"):
         out["stale"] = None
     pk = j.get("per_kernel", {})
     sched = pk.get(schedule) or pk.get("fused", {})
-    fused = [(k, v) for k, v in sched.items() if k.startswith(("cspn_prop", "cspn3_resident")) and "hbm_bytes_corrected" in v]
+    # every kernel of the forward counts: the prepare / softmax pass, each propagation launch, the metrics reduction.
+    # A forward runs its prepare (or its metrics, or its single resident launch) exactly once, so the smallest dispatch
+    # count over the schedule's kernels is the number of forwards profiled; `launches_of_rarest` corrects that when even
+    # the rarest kernel runs several times per forward (a resident schedule chunked over several launches).
+    allk = [(k, v) for k, v in sched.items() if k.startswith("cspn") and "hbm_bytes_corrected" in v]
+    fused = [(k, v) for k, v in allk if k.startswith(("cspn_prop", "cspn3_resident", "cspnk_resident"))]
     if fused:
-        n_fwd = min(v["_dispatches_FETCH_SIZE"] for _, v in fused)       # every instance runs >= once per forward
+        n_fwd = min(v["_dispatches_FETCH_SIZE"] for _, v in allk) / max(1, launches_of_rarest)
         out["fused_per_launch"] = {k: v["hbm_bytes_corrected"] for k, v in fused}
-        out["fused_bytes_per_forward"] = sum(v["hbm_bytes_corrected"] * v["_dispatches_FETCH_SIZE"] for _, v in fused) / n_fwd
+        out["per_kernel_per_forward"] = {k: [v["hbm_bytes_corrected"], v["_dispatches_FETCH_SIZE"] / n_fwd] for k, v in allk}
+        out["fused_bytes_per_forward"] = sum(v["hbm_bytes_corrected"] * v["_dispatches_FETCH_SIZE"] for _, v in allk) / n_fwd
     step = [(k, v) for k, v in pk.get("step", {}).items() if k.startswith("cspn_prop") and "hbm_bytes_corrected" in v]
     if step:                                                             # the plain streaming instance dominates
         out["step_bytes_per_launch"] = max(step, key=lambda kv: kv[1]["_dispatches_FETCH_SIZE"])[1]["hbm_bytes_corrected"]
@@ -133,6 +139,31 @@ def load_train_traffic(tag):
         return None
 
 
+def host_cpu_budget():
+    """Cores this process may use: the scheduler affinity mask and the cgroup CPU quota (v2 cpu.max / v1 cfs quota), next
+    to os.cpu_count() (which counts the machine's threads whatever the container is allowed)."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.999)))
+    return {"os_cpu_count": logical, "sched_affinity": affinity, "cgroup_cpu_quota": quota, "usable": usable}
+
+
 def cpu_baseline(wl, budget_s=16.0):
     """The reference's CPU op mix (oracle/ref_plumbing_torch.py, a port validated bit-identical to the imported
     reference) on this box's host cores, on a bounded sample of the same workload: single frames and a
@@ -141,7 +172,8 @@ def cpu_baseline(wl, budget_s=16.0):
     batch and threads); the best rate is reported."""
     from oracle import ref_plumbing_torch as plumb
     from oracle import c_oracle
-    cores = os.cpu_count() or 1
+    host = host_cpu_budget()
+    cores = host["usable"]          # what this process may actually run on — not os.cpu_count()
     H, W, T = wl["H"], wl["W"], wl["T"]
     torch.manual_seed(0)
 
@@ -208,7 +240,7 @@ def cpu_baseline(wl, budget_s=16.0):
     except OSError:
         pass
     one = [t for t in tried if t["threads"] == 1]
-    out = {"value": best[0], "unit": "depth-maps/s", "cores": best[1], "kind": "port", "host_cores": cores,
+    out = {"value": best[0], "unit": "depth-maps/s", "cores": best[1], "kind": "port", "host_cores": cores, "host_cpu_budget": host,
            "cpu_model": model, "single_thread_value": max(t["maps_per_s"] for t in one) if one else None,
            "all_threads_leg": all_cores,
            "sample": "%d forward(s) of %d frame(s) %dx%d, T=%d (median, after warm-up) with %d of %d host threads; "
@@ -378,6 +410,8 @@ def main():
     if args.batch > 0:
         wl["B"] = args.batch
         wl["name"] += " [batch overridden to %d]" % args.batch
+    if world > n_dev:
+        F.set_resident("off")      # several ranks share one GPU (gloo dry run): resident launches must own the device
     if args.workload == "train":
         return run_train(args, wl, world, rank, local_rank, device)
     strong = args.workload == "kitti"
@@ -412,8 +446,6 @@ def main():
                                        target[:, 0].contiguous(), pkg.evaluation.new_accumulator(device)))
             del w_
         module.plan = plan
-    if world > n_dev:
-        F.set_resident("off")      # several ranks share one GPU (gloo dry run): resident launches must own the device
     w_torch_dtype = torch.float16 if wl["dtype"] == "f16" else torch.float32
     eff_plan = F.resolve_plan(K, B_local, wl["H"], wl["W"], T, False,
                               plan if K == 3 else F.dtype_default_plan(K, w_torch_dtype, plan))
@@ -541,11 +573,11 @@ def main():
     # measured HBM traffic (rocprofv3 --pmc passes, tools/r02_profile_session.sh -> tools/pmc_traffic.py): NOT collected by this
     # run — counters need their own rocprofv3 passes — so the figures are quoted from the committed summary together with
     # the source digest of the kernels they were measured on (`traffic_stale` = the kernels changed since).
-    pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""), "fused" if res_plan is not None else "multi")
-    if res_plan is not None and pmc["fused_per_launch"]:    # one resident instance, `launches` dispatches of it per forward
-        pmc["fused_bytes_per_forward"] = sum(pmc["fused_per_launch"].values()) * res_plan["launches"]
+    pmc = load_pmc_traffic(args.workload + ("_sparse" if args.sparse else ""), "fused" if res_plan is not None else "multi",
+                           res_plan["launches"] if res_plan is not None else 1)
     if args.batch > 0 or world > 1:                     # the committed passes were measured on the workload's own batch on one GPU
         pmc = dict(pmc, step_bytes_per_launch=None, fused_bytes_per_forward=None, fused_per_launch=None, sq=None,
+                   per_kernel_per_forward=None,
                    source=None if pmc["source"] is None else pmc["source"] + " [not applicable: batch overridden / sharded]")
 
     # ---- the north-star schedule: ONE launch per propagation step (S = 1), measured in the same process.  This is the
@@ -595,6 +627,54 @@ def main():
             dt1 = time.perf_counter() - t0
             F.set_event_log(None)
         del w1
+        # ... and the same kernel where the Infinity Cache cannot help (SURVEY.md 8d asks for both): two input sets of
+        # `Bc` frames each, every launch's own bytes >= 300 MB (> the 256 MiB cache), launches alternating between the
+        # sets so that nothing a launch reads or writes was touched by the launch before it
+        cold1 = None
+        try:
+            px = wl["H"] * wl["W"]
+            Bc = max(B_local, -(-300_000_000 // (bytes_px_step * px)))
+            with torch.no_grad():
+                csets = []
+                for i in range(2):
+                    gc, dc, sc, _ = make_inputs(wl, Bc, device, seed=777 + i, sparse=args.sparse)
+                    wc = (F.cspn3_prepare(gc)[0] if K == 3 else F.pac_prepare(gc)[0])
+                    csets.append((wc, dc[:, 0].contiguous(), None if sc is None else sc[:, 0].contiguous()))
+                    del gc, dc, sc
+                best_c, pc = float("inf"), None
+                for cand in F.candidate_plans(K, wl["H"], wl["W"], 1):
+                    if cand["steps_per_launch"] != 1:
+                        continue
+                    try:
+                        for wc, dc, sc in csets:
+                            F.propagate(wc, dc, sc, K, 1, bl1, plan=cand)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            for wc, dc, sc in csets:
+                                F.propagate(wc, dc, sc, K, 1, bl1, plan=cand)
+                        e1.record()
+                        e1.synchronize()
+                    except RuntimeError:
+                        continue
+                    if e0.elapsed_time(e1) < best_c:
+                        best_c, pc = e0.elapsed_time(e1), cand
+                nrep = 20
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(nrep):
+                    for wc, dc, sc in csets:
+                        F.propagate(wc, dc, sc, K, 1, bl1, plan=pc)
+                e1.record()
+                e1.synchronize()
+                us_c = e0.elapsed_time(e1) * 1e3 / (2 * nrep)
+            algc = bytes_px_step * Bc * px
+            cold1 = {"batch": Bc, "input_sets": 2, "bytes_per_launch": algc, "footprint_MB": 2 * algc / 1e6,
+                     "avg_launch_us": us_c, "achieved": algc / us_c / 1e3, "frac": algc / us_c / 1e3 / HBM_PEAK_GBS, "plan": pc,
+                     "note": "one S=1 launch per call, alternating between two input sets (launch gaps included)"}
+            del csets
+        except RuntimeError as e:                                      # noqa: BLE001
+            cold1 = {"error": str(e).splitlines()[0][:160]}
         ms1 = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ev1)
         nl1 = sum(n for _, _, n, _ in ev1)
         alg1 = bytes_px_step * B_local * wl["H"] * wl["W"]
@@ -606,6 +686,7 @@ def main():
                     "algorithmic_bytes_per_launch": alg1, "bytes_per_px_step": bytes_px_step,
                     "avg_launch_us": ms1 * 1e3 / nl1, "launches_timed": nl1, "steps_per_launch": 1,
                     "maps_per_s_forward_only": B_local * n1 / dt1, "plan": p1,
+                    "frac_cache_cold": None if not cold1 or "frac" not in cold1 else cold1["frac"], "cache_cold": cold1,
                     "note": "HIP events on the launch stream around each T-launch loop (launch gaps included) / T; "
                             "SURVEY.md 8(d): (K^2+1)*sizeof(T) bytes per pixel per step"}
 
@@ -631,10 +712,13 @@ def main():
              "compulsory_bytes_per_forward": compulsory,
              "hbm_traffic_bytes_per_forward": pmc["fused_bytes_per_forward"],
              "hbm_traffic_per_launch": pmc["fused_per_launch"],
+             "hbm_traffic_per_kernel_bytes_x_launches_per_forward": pmc["per_kernel_per_forward"],
              "traffic_source": pmc["source"], "traffic_stale": pmc["stale"],
              "propagation_us_per_forward_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)]}
     if pmc["fused_bytes_per_forward"] and n_launch:
-        fwd_s = avg_launch_s * launches_fwd
+        # the traffic is that of the WHOLE forward (prepare / softmax pass, every propagation launch, metrics), so it is
+        # priced against the whole step's time (max over ranks of the timed region / steps), not the propagation launches'
+        fwd_s = elapsed / args.steps
         fused["hbm_GBs_on_measured_traffic"] = pmc["fused_bytes_per_forward"] / fwd_s / 1e9
         fused["frac_hbm_on_measured_traffic"] = fused["hbm_GBs_on_measured_traffic"] / HBM_PEAK_GBS
         fused["traffic_over_compulsory"] = pmc["fused_bytes_per_forward"] / compulsory

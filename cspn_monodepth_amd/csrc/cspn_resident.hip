@@ -633,6 +633,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
+                // Poison what this tile will never produce: its part of the refined depth (or of the last history plane —
+                // d_T in the training forward, G_0 in the reverse sweep) becomes NaN, so that a result consumed before the
+                // host has looked at the error word is visibly wrong instead of stale allocator memory.
+                {
+                    const float qnan = __uint_as_float(0x7fc00000u);
+                    float* const pz = HIST ? uniform_ptr(a.hist + (size_t)(a.T - 1) * plane + (size_t)b * HW) : dout;
+                    unsigned o0 = (unsigned)(yq0L * W + xqL);
+                    asm volatile("" : "+v"(o0));
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        if ((interior >> i) & 1u) st4(at32(pz, o0 + (unsigned)(i * W)), make_float4(qnan, qnan, qnan, qnan));
+                }
                 return;
             }
         }
@@ -827,6 +839,7 @@ int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_re
     ResGeom g;
     if (T < 1 || !resident_geometry(B, H, W, T, blend, n_cu, out->steps_per_phase, &g))
         return fail("cspn3_resident_plan: no resident tiling for B=%d %dx%d T=%d on %d CUs (W %% 4 == 0 needed)", B, H, W, T, n_cu);
+    if (ceil_div(T, g.S) > 255) return fail("cspn3_resident_plan: T=%d in %d-step phases is more than 255 phases", T, g.S);
     out->steps_per_phase = g.S; out->tiles_x = g.tiles_x; out->tiles_y = g.tiles_y; out->tile_w = g.tw; out->tile_h = g.th;
     out->quads_per_thread = g.nq; out->threads = RES_THREADS; out->images_per_launch = g.imgs_per_launch;
     out->launches = g.launches; out->lds_bytes = (int)g.lds_bytes; out->n_cu = n_cu;
@@ -886,6 +899,7 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         return fail("cspn3_forward_resident: tensors must be 16-byte aligned");
     if (W_valid < 0 || W_valid > W) return fail("cspn3_forward_resident: W_valid=%d outside (0, W=%d]", W_valid, W);
     if (seq == 0 || seq > 0x7fffff00u) return fail("cspn3_forward_resident: seq must be in [1, 2^31 - 256]");
+
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ncu = cu_count();
     if (ncu <= 0) return fail("cspn3_forward_resident: no device");
@@ -911,6 +925,10 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     } else if (!resident_geometry(B, H, W, T, blend, ncu, rp.steps_per_phase, &g)) {
         return fail("cspn3_forward_resident: no resident tiling for B=%d %dx%d T=%d", B, H, W, T);
     }
+    // a tile that finished phase p publishes seq + p + 1, and the next call on the workspace brings seq + 256: more than
+    // 255 phases would let one call's flags satisfy the next call's waits
+    if (ceil_div(T, g.S) > 255)
+        return fail("cspn3_forward_resident: T=%d in %d-step phases is more than 255 phases (use the multi-launch schedule)", T, g.S);
     ResArgs a{};
     a.g = static_cast<const float*>(guidance); a.g_bs = bs; a.g_cs = cs;
     a.d0 = static_cast<const float*>(d0); a.sparse = static_cast<const float*>(sparse); a.out = static_cast<float*>(out);

@@ -427,7 +427,9 @@ __global__ __launch_bounds__(256, (HOIST ? 1 : 4)) void pac_conv2d_tiled_h8(cons
             for (int i = 0; i < K; ++i) {
                 if (!HOIST) {
                     if (i + 1 < K) load_taps(a.CK == 1 ? 0 : c, (i + 1) * K, K, ((i + 1) & 1) * K);
-                    else if (more) load_taps(a.CK == 1 ? 0 : c + 1, 0, K, ((i + 1) & 1) * K);   // K odd: row 0 of the next channel lands in half 0
+                    // K is odd: the last row sits in half 0, so row 0 of the NEXT channel is prefetched into the free half 1
+                    // and moved to half 0 (where every channel expects its row 0) at the channel boundary below
+                    else if (more) load_taps(a.CK == 1 ? 0 : c + 1, 0, K, K);
                 }
                 float win[4 * NQUAD];
 #pragma unroll
@@ -447,6 +449,11 @@ __global__ __launch_bounds__(256, (HOIST ? 1 : 4)) void pac_conv2d_tiled_h8(cons
             *reinterpret_cast<__half2*>(&o.z) = __floats2half2_rn(acc[4], acc[5]);
             *reinterpret_cast<__half2*>(&o.w) = __floats2half2_rn(acc[6], acc[7]);
             *reinterpret_cast<uint4*>(dst + ((size_t)b * a.C + c) * dplane + dpix) = o;
+            if (!HOIST && more) {
+                static_assert(K & 1, "the row double-buffer assumes an odd K");
+#pragma unroll
+                for (int t = 0; t < K; ++t) kr[t] = kr[K + t];
+            }
         }
         if (more) commit(buf ^ 1);
         __syncthreads();

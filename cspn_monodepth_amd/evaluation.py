@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import functional as _F
 
 METRIC_NAMES = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
 N_SUMS = 10   # {inv^2, inv, diff^2, diff, diff/t, |dlog10|, #<1.25, #<1.25^2, #<1.25^3, n}
@@ -63,6 +64,12 @@ def metric_sums(pred, target, out=None):
 
 def finalize_metrics(sums):
     """float64[10] sums -> dict of the reference's 10 metrics + 'count'."""
+    # the numbers are about to be used on the host: a weight-resident launch that timed out must raise here, not be
+    # averaged in (a device tensor is waited for first; a host tensor has been through a synchronising copy already)
+    if getattr(sums, "is_cuda", False):
+        _F.ensure_resident_ok(sums.device)
+    else:
+        _F.check_resident_errors()
     if hasattr(sums, "dim") and sums.dim() == 2:
         sums = sums.sum(0)
     s = [float(v) for v in sums]
@@ -97,9 +104,8 @@ class BatchAverageMeter(object):
         self.sums = {k: 0.0 for k in METRIC_NAMES}
 
     def update(self, batch_sums, n=1):
+        # (a batch without valid pixels records NaN, as the reference's Result.evaluate would)
         fin = finalize_metrics(batch_sums.cpu() if hasattr(batch_sums, "cpu") else batch_sums)
-        if fin["count"] == 0:            # the reference would record NaN for a batch without valid pixels; so do we
-            pass
         self.count += n
         for k in METRIC_NAMES:
             self.sums[k] += n * fin[k]
@@ -112,12 +118,18 @@ class BatchAverageMeter(object):
 
 
 def all_gather_metric_sums(sums, group=None):
-    """All-gather the per-rank sums (world x 10 float64) and add them.  Works with gloo (CPU) and nccl/RCCL."""
+    """All-gather the per-rank sums (world x 10 float64) and add them.  Works with gloo (CPU) and nccl/RCCL.
+
+    This is where an evaluation loop hands its numbers on, so it first waits for the weight-resident launches that
+    produced them and raises if one timed out (functional.ensure_resident_ok) — also for the last batch of the loop,
+    which no later launch would check.  Returns (total [10], per_rank [world, 10]), independent tensors."""
+    if sums.is_cuda:
+        _F.ensure_resident_ok(sums.device)
     if sums.dim() == 2:
         sums = sums.sum(0)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        total = sums.clone()                              # one rank: nothing to gather (the per-rank view shares `total`)
-        return total, total.unsqueeze(0)
+        total = sums.clone()                              # one rank: nothing to gather
+        return total, total.clone().unsqueeze(0)
     world = dist.get_world_size(group)
     src = sums.contiguous()
     if sums.is_cuda and dist.get_backend(group) == "gloo":

@@ -508,8 +508,12 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
 _RESIDENT_MODE = os.environ.get("CSPN_RESIDENT", "auto")      # "auto" | "on" | "off"
 _RES = {}                 # device index -> state dict
 _RES_LOCK = threading.Lock()
-_RES_SEQ_STEP = 8
+# Flag values of one call span seq+1 .. seq+n_phase-1 (a tile that finished phase p publishes seq + p + 1) and the engine
+# refuses more than 255 phases, so a step of 256 keeps the values of consecutive calls on one workspace disjoint
+# (include/cspn_hip.h: "grows by at least 256").
+_RES_SEQ_STEP = 256
 _RES_SEQ_MAX = (1 << 31) - 4096
+_RESIDENT_SPIN_LIMIT = 0   # test hook: polls before a neighbour wait gives up (0 = the engine's default, ~seconds)
 
 
 def set_resident(mode):
@@ -536,9 +540,18 @@ def _resident_state(dev):
     if st is None:
         host_err = torch.zeros(4, dtype=torch.int32).pin_memory()
         st = _RES[dev.index] = dict(seq=_RES_SEQ_STEP, work={}, host_err=host_err, host_err_np=host_err.numpy(),
-                                    host_err_ptr=ctypes.c_void_p(host_err.data_ptr()),
+                                    host_err_ptr=ctypes.c_void_p(host_err.data_ptr()), dirty=False,
                                     last_stream=None, n_cu=torch.cuda.get_device_properties(dev).multi_processor_count)
     return st
+
+
+def _device_is_oversubscribed():
+    """More ranks of this job than GPUs on the node (torchrun's LOCAL_WORLD_SIZE): several processes share a device, and
+    their resident launches could starve each other — mode "auto" then keeps to the multi-launch schedule."""
+    try:
+        return int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1)
+    except ValueError:
+        return False
 
 
 _RES_PLAN_CACHE = {}      # (B, H, W, T, blend, device index, mode) -> (plan dict | None, ctypes plan | None)
@@ -549,7 +562,10 @@ def _resident_plan_cached(B, H, W, T, blend, dev):
     hit = _RES_PLAN_CACHE.get(key)
     if hit is None:
         n_cu = _resident_state(dev)["n_cu"]
-        rp = resident_plan(B, H, W, T, blend, n_cu) if _RESIDENT_MODE == "on" else resident_pays(B, H, W, T, blend, dev)
+        if _RESIDENT_MODE == "on":
+            rp = resident_plan(B, H, W, T, blend, n_cu)
+        else:
+            rp = None if _device_is_oversubscribed() else resident_pays(B, H, W, T, blend, dev)
         cp = None
         if rp is not None:
             cp = _lib.cspn_resident_plan()
@@ -594,15 +610,64 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
 
 def check_resident_errors(dev=None):
     """Raise if a resident launch on `dev` (default: every device used so far) gave up waiting for a neighbouring tile —
-    i.e. its workgroups were not co-resident because something else held the GPU for seconds.  Called at the start of
-    every resident forward; the refined depth of the failed call is incomplete."""
+    i.e. its workgroups were not co-resident because something else held the GPU for seconds.  Only looks at the error
+    words the launches that have FINISHED wrote: call it after a synchronisation that covers them, or use
+    ensure_resident_ok, which synchronises first.  The result of the failed call is incomplete (its missing tiles are
+    NaN).  Called at the start of every resident launch, by ensure_resident_ok, and at the end of a backward pass."""
     for idx, st in list(_RES.items()):
         if (dev is None or dev.index == idx) and st["host_err_np"][0] != 0:
             st["host_err_np"][0] = 0
+            st["dirty"] = False
             raise RuntimeError("cspn3_forward_resident on cuda:%d timed out waiting for a neighbouring tile (the GPU was "
                                "shared with another long-running tenant, so the launch was not co-resident); the output of "
                                "that call is incomplete.  Use cspn_monodepth_amd.functional.set_resident('off') or "
                                "CSPN_RESIDENT=off when the device is shared." % idx)
+
+
+def ensure_resident_ok(dev=None):
+    """Wait for the resident launches issued so far on `dev` (default: every device) and raise if one of them timed out.
+    This is what every consumer of a result on the host calls before it trusts the numbers — evaluation.
+    all_gather_metric_sums / finalize_metrics do; a training step gets the equivalent at the end of its backward pass
+    (CSPN3Function.backward).  Costs nothing when no resident launch is pending (no synchronisation then)."""
+    for idx, st in list(_RES.items()):
+        if dev is not None and dev.index != idx:
+            continue
+        if st["dirty"]:
+            last = st["last_stream"]
+            if last is not None and not torch.cuda.is_current_stream_capturing():
+                last.synchronize()
+            st["dirty"] = False
+    check_resident_errors(dev)
+
+
+def mark_resident_pending(t=None):
+    """A HIP-graph replay may have run resident launches this module did not see: make the next ensure_resident_ok on
+    that device wait for its stream."""
+    dev = t.device if t is not None and t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    st = _RES.get(dev.index)
+    if st is not None:
+        st["dirty"] = True
+        st["last_stream"] = torch.cuda.current_stream(dev)
+
+
+class _ResidentCheckpoint(object):
+    """An event behind the resident launches issued so far on a device; `wait_and_check` synchronises on it (not on the
+    stream: whatever was enqueued later keeps running) and raises if one of those launches timed out."""
+    __slots__ = ("dev", "event")
+
+    def __init__(self, dev):
+        self.dev = dev
+        st = _resident_state(dev)
+        cur = torch.cuda.current_stream(dev)
+        last = st["last_stream"]
+        if last is not None and last != cur:
+            cur.wait_stream(last)
+        self.event = torch.cuda.Event()
+        self.event.record(cur)
+
+    def wait_and_check(self):
+        self.event.synchronize()
+        check_resident_errors(self.dev)
 
 
 def _resident_launch(dev, B, H, W, T, launch):
@@ -638,18 +703,19 @@ def _resident_launch(dev, B, H, W, T, launch):
             if len(st["work"]) > 16:
                 st["work"].clear()
             work = st["work"][key] = torch.zeros((L.cspn3_resident_workspace_bytes(B, H, W),), dtype=torch.uint8, device=dev)
-        if st["seq"] > _RES_SEQ_MAX:                    # flag values wrap: start over on clean workspaces
-            for w_ in st["work"].values():
-                w_.zero_()
-            st["seq"] = _RES_SEQ_STEP
-        seq = st["seq"]
-        st["seq"] = seq + _RES_SEQ_STEP
         with _device_guard(dev):
             cur = torch.cuda.current_stream(dev)
             last = st["last_stream"]
             if last is not None and last != cur:
                 cur.wait_stream(last)                   # resident launches never overlap on a device
             st["last_stream"] = cur
+            st["dirty"] = True
+            if st["seq"] > _RES_SEQ_MAX:                # flag values wrap: start over on clean workspaces (zeroed on `cur`,
+                for w_ in st["work"].values():          # behind every earlier resident launch)
+                    w_.zero_()
+                st["seq"] = _RES_SEQ_STEP
+            seq = st["seq"]
+            st["seq"] = seq + _RES_SEQ_STEP
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
@@ -660,13 +726,23 @@ def _resident_launch(dev, B, H, W, T, launch):
     return ok
 
 
+def _with_spin_limit(cp):
+    """The cached ctypes plan, or a copy carrying the test hook's spin limit."""
+    if not _RESIDENT_SPIN_LIMIT or cp is None:
+        return cp
+    c2 = _lib.cspn_resident_plan()
+    ctypes.memmove(ctypes.byref(c2), ctypes.byref(cp), ctypes.sizeof(c2))
+    c2.spin_limit = int(_RESIDENT_SPIN_LIMIT)
+    return c2
+
+
 def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
     """Reverse sweep of the backward as one weight-resident launch per chunk: ghist [T,B,H,W] (G_{T-1} .. G_0)."""
     dev = _require_device(w8, g_T, sparse_f32)
     B, H, W = g_T.shape
     L = _lib.lib()
     ghist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
-    rp = _resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1]
+    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1])
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspn3_transposed_resident(_p(w8), _p(g_T), _p(sparse_f32), _p(ghist), _p(work), seq, host_err_ptr, B, H, W,
@@ -702,7 +778,8 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
     else:
-        rp = _resident_plan_cached(B, H, W, int(T), int(blend), dev)[1]      # found once per shape: the C side skips its search
+        # found once per shape: the C side skips its search
+        rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(blend), dev)[1])
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspn3_forward_resident(_p(guidance), guidance.stride(0), guidance.stride(1), _p(d0), _p(sparse), _p(out),
                                         _p(hist), _p(w8), _p(S_out), _p(work), seq, host_err_ptr, B, H, W, int(valid_w),
@@ -785,6 +862,24 @@ def _grad_weights(w, K, T, d0, dhist, sparse, g_T, ghist):
 
 
 # ------------------------------------------------------------------------------------------------ autograd
+def _check_resident_at_end_of_backward(dev):
+    """A training step must not apply gradients built on a resident launch that timed out (the forward with history, or
+    the reverse sweep just enqueued).  Waiting here would stall the host in the middle of the backward pass; instead an
+    event is recorded behind those launches and the autograd engine runs the check when the whole backward pass has
+    been enqueued (queue_callback: before `.backward()` returns, i.e. before any optimiser step) — by then the CSPN
+    kernels, the first of the backward pass, have long finished, so the wait is free in a real model.  The reference
+    re-raises worker errors the same way, never swallowing them (network/libs/base/encoding.py:172-174, :193-194)."""
+    st = _RES.get(dev.index)
+    if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing():
+        return
+    cp = _ResidentCheckpoint(dev)
+    st["dirty"] = False            # everything issued so far is covered by the checkpoint
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(cp.wait_and_check)
+    except RuntimeError:           # not inside an engine-driven backward (a direct call of .backward on the ctx): check now
+        cp.wait_and_check()
+
+
 class _NoGradCtx(object):
     """Stand-in ctx for inference calls that skip torch.autograd.Function.apply (saves ~10 us of host time)."""
     needs_input_grad = (False,) * 8
@@ -835,6 +930,7 @@ class CSPN3Function(torch.autograd.Function):
         T = ctx.prop_time
         L = _lib.lib()
         g_T, ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
+        _check_resident_at_end_of_backward(g.device)
         gg = torch.empty_like(g)
         if _tail_vector_ok(W, g, w8, S, d0, sp, hist, gg) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
             gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)

@@ -7,6 +7,8 @@ the per-call host work (Python, allocator, three launches), which is what bounds
 """
 import torch
 
+from . import functional
+
 
 class GraphedForward(object):
     """graphed = GraphedForward(fn, *example_tensors);  out = graphed(*tensors)   (same shapes / dtypes).
@@ -27,9 +29,19 @@ class GraphedForward(object):
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *tensors, copy_inputs=True):
+        # a replayed weight-resident launch that timed out must not go unnoticed: the previous replay's error word is
+        # looked at before the next one (free: a pinned host word); `synchronize()` below checks the last one
+        functional.check_resident_errors()
         if copy_inputs:
             for dst, src in zip(self.static_in, tensors):
                 if dst is not None and src is not None and dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        functional.mark_resident_pending(self.static_out)
+        return self.static_out
+
+    def synchronize(self):
+        """Wait for the last replay and raise if a weight-resident launch inside it timed out; returns the output."""
+        torch.cuda.current_stream().synchronize()
+        functional.check_resident_errors()
         return self.static_out

@@ -231,10 +231,12 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * same time (a second process on the GPU, or a second stream of this process): callers serialise resident launches per
  * device (cspn_monodepth_amd/functional.py chains them with events).  The neighbour wait is bounded (seconds): on
  * time-out the launch stores 1 to status word 1 of the workspace (and to *host_err, a host-mapped word, if given),
- * drains, and leaves `out` incomplete — the caller must check the word before trusting later results.
+ * drains, and leaves `out` incomplete — the tiles that gave up are filled with NaN (in `out`, or in the last history
+ * plane) — and the caller must check the word before trusting the result (functional.ensure_resident_ok).
  *
  * work: cspn3_resident_workspace_bytes(B,H,W) bytes, ZERO-initialised once by the caller, then only ever passed to this
- * entry.  seq: any value in [1, 2^31-256] that grows by at least 8 from one call on the same workspace to the next.
+ * entry.  seq: any value in [1, 2^31-256] that grows by at least 256 from one call on the same workspace to the next
+ * (a tile that finished phase p publishes seq + p + 1; at most 255 phases per call, i.e. T <= 1020 with 4-step phases).
  * Layout: the two exchange planes [2][B,H,W] f32 (never need initialising), rounded up to 16 bytes, then the control words
  * (status + tile flags).  Re-zeroing the control words makes any seq valid again: a captured HIP graph records that memset
  * in front of the launch and replays with a constant seq. */

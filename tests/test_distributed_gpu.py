@@ -52,3 +52,25 @@ def test_bench_two_ranks_on_one_gpu_kitti():
     # thread differently from the shards' multi-launch plan: equal up to summation order
     for k in ("rmse", "absrel", "delta1"):
         assert abs(m1[k] - m2[k]) <= 1e-6 * abs(m1[k]), (k, m1[k], m2[k])
+
+
+def test_ddp_training_step_two_ranks():
+    """BASELINE config 5's data-parallel branch at world size 2 (VERDICT r2 missing #3): DistributedDataParallel +
+    nn.SyncBatchNorm around the re-hosted unet_cspn_nyu with the HIP CSPN in forward and backward, two processes on the one
+    GPU (gloo).  The worker asserts: DDP gradients = mean of the ranks' own gradients, SyncBN statistics and parameters
+    identical across ranks after optimiser steps, the CSPN pair inside the model equals the oracle.  Replaces
+    libs/trainers/multi_gpu_trainer.py:32-37.  (RCCL proper needs >= 2 GPUs: never run here — DESIGN.md §5.)"""
+    out = _torchrun(2, 29671, [os.path.join("tests", "dist_ddp_worker.py"), "gloo", "2"], timeout=1500)
+    assert "DDP_CHECK_OK world=2" in out, out[-2000:]
+
+
+def test_bench_train_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 --backend gloo --workload train: the driver's launch line for config 5 through bench.py's own
+    DDP + SyncBatchNorm branch (bench.py run_train), oversubscribing the one GPU."""
+    out = _torchrun(2, 29683, ["bench.py", "--gpus", "2", "--backend", "gloo", "--workload", "train", "--steps", "2",
+                               "--warmup", "1"], timeout=1500)
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 6
+    assert "DDP x2" in d["config"]["parallelism"] and d["value"] > 0
+    assert all(v == v and abs(v) < 1e6 for v in d["loss_first_last"])
+    assert d["cspn_module"]["forward_us_p50"] > 0 and d["cspn_module"]["backward_us_p50"] > 0

@@ -334,3 +334,30 @@ def test_fp16_eight_pixel_kernels(K, C, CK, Ho, Wo, same):
         assert nmax(out, want) <= 2e-3 and nmax(gi, wgi) <= 2e-3 and nmax(gk, wgk) <= 2e-3, (scalar, nmax(out, want), nmax(gi, wgi), nmax(gk, wgk))
     # same fp32 accumulation order per output in both forward kernels and an exact product in dL/dkernel: identical halfs
     assert np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("K", [3, 5])
+def test_fp16_eight_pixel_kernel_several_channels_per_workgroup(K):
+    """pac_conv2d_tiled_h8 with a per-channel kernel (CK == C) and MORE THAN ONE channel per workgroup (cchunk > 1: the
+    launcher stops splitting channels once tiles x batch x chunks >= 4096).  The tap rows are double-buffered across the
+    channel boundary — row 0 of the next channel is prefetched while the last row of the current one is applied — which
+    round 2 got wrong for every channel after a workgroup's first.  Too large for the numpy oracle (the kernel
+    tensor is ~0.6 GB): the tiled kernel must equal the generic one, which accumulates in the same order, half for half,
+    and a few outputs are checked against a direct fp64 evaluation."""
+    B, C, Ho, Wo = 64, 5, 64, 512                      # 16 tiles x 64 images -> 4 chunks of (2, 2, 1) channels
+    g = torch.Generator(device="cuda").manual_seed(900 + K)
+    x = torch.randn(B, C, Ho, Wo, device="cuda", generator=g).half()
+    kern = (torch.randn(B, C, K, K, Ho, Wo, device="cuda", generator=g) * 0.3).half()
+    outs = {}
+    with torch.no_grad():
+        for scalar in (0, 1):
+            with force_generic(scalar):
+                outs[scalar] = pac.conv2d(x, kern, K, 1, K // 2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    xp = torch.nn.functional.pad(x.double(), (K // 2,) * 4)
+    rng = np.random.default_rng(5)
+    for _ in range(64):
+        b, c, y, xx = (int(rng.integers(0, n)) for n in (B, C, Ho, Wo))
+        want = float((xp[b, c, y:y + K, xx:xx + K] * kern[b, c, :, :, y, xx].double()).sum())
+        assert abs(float(outs[0][b, c, y, xx]) - want) <= 2e-3 * max(1.0, abs(want)), (b, c, y, xx)
