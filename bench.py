@@ -454,6 +454,9 @@ def main():
     if K == 3 and B_local > 0:                              # (also under --graph on: the capture records the launch + a flag memset)
         res_plan = F.resident_supported(g, d[:, 0], None if s is None else s[:, 0], T, plan,
                                         None if args.no_metrics else target[:, 0])
+    if K != 3 and B_local > 0 and plan is None:             # K x K: weight-resident launches for fp16 guidance (cspnk_forward_resident)
+        res_plan = F.pac_resident_supported(g, d[:, 0].contiguous(), None if s is None else s[:, 0].contiguous(), T, plan,
+                                            None if args.no_metrics else target[:, 0].contiguous())
     if res_plan is not None:
         eff_plan = dict(res_plan, schedule="resident", steps_per_launch=T)
         eff_plan.pop("debug_stamps", None)
@@ -699,8 +702,9 @@ def main():
     # plane, + the target plane the fused metrics read)
     compulsory = B_local * wl["H"] * wl["W"] * ((K * K - 1) * esz_g + 2 * esz + (esz if args.sparse else 0) +
                                                 (0 if args.no_metrics else esz))
-    fused = {"kernel": ("cspn3_resident<%d,...> (ONE launch, weights resident in VGPRs for all %d steps, %d-step phases)" % (
-                 eff_plan["quads_per_thread"], T, eff_plan["steps_per_phase"])) if res_plan is not None else
+    fused = {"kernel": (("cspn3_resident<%d,...>" if K == 3 else "cspnk_resident<%d,%%d,...>" % K) % eff_plan["quads_per_thread"] +
+                        " (%d launch(es) of whole images, weights resident in VGPRs for all %d steps, %d-step phases)" % (
+                            eff_plan["launches"], T, eff_plan["steps_per_phase"])) if res_plan is not None else
              "cspn_prop_fused<%d,...> S=%d (%d launches per forward)" % (K, S, launches_fwd),
              "bound": "valu+lds (temporal blocking: the step loop runs out of LDS/VGPRs, HBM traffic is below the "
                       "algorithmic bytes)" if S > 1 else "hbm",

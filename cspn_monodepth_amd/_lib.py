@@ -15,12 +15,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 4          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 5          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -28,6 +28,7 @@ EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
     "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn_propagate_transposed", "cspn3_propagate_from_guidance",
     "cspn_transpose_weights", "cspn3_resident_plan", "cspn3_resident_workspace_bytes", "cspn3_forward_resident", "cspn3_transposed_resident",
+    "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
     "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
@@ -140,6 +141,11 @@ def _declare(lib):
                                            ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn3_transposed_resident.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, ci,
                                               ctypes.POINTER(cspn_resident_plan), vp]
+    lib.cspnk_resident_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_resident_plan)]
+    lib.cspnk_resident_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.cspnk_resident_workspace_bytes.restype = cs
+    lib.cspnk_forward_resident.argtypes = [vp, ci, vp, vp, vp, ci, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, vp, vp, ci,
+                                           ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
@@ -158,7 +164,8 @@ def _declare(lib):
     lib.cspn_unpool2d_backward.argtypes = [vp, vp, ci, cl, ci, ci, ci, ci, ci, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes", "cspn3_resident_workspace_bytes"):
+        if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes", "cspn3_resident_workspace_bytes",
+                        "cspnk_resident_workspace_bytes"):
             fn.restype = ci
     return lib
 

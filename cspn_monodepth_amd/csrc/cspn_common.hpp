@@ -99,6 +99,33 @@ __device__ __forceinline__ void div8_shared_reciprocal(const float (&a)[8], floa
 #endif
 }
 
+// exp(x) for x <= 0 (the max-subtracted logits) on the hardware exponential: v_exp_f32 is 2^t to 1 ulp; the product
+// x * log2(e) is formed in two pieces (fma recovers its rounding error) so that the result stays within ~2 ulp of
+// expf for every x instead of drifting by |x| * 2^-24.  libm's expf made both prepare kernels VALU-bound (~25 VALU
+// operations per call, 24 calls per pixel at K = 5: 33.6 us for a pass whose HBM floor is 20 us).
+__device__ __forceinline__ float exp_nonpositive(float x) {
+    const float L2E = 1.44269502162933349609375f;          // float(log2(e))
+    const float L2E_LO = 1.925963033500011e-8f;            // log2(e) - float(log2(e))
+    const float t = x * L2E;
+    const float r = fmaf(x, L2E, -t) + x * L2E_LO;         // what t lost
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147180559945f, e);             // 2^(t+r) = 2^t (1 + r ln 2 + ...)
+}
+__device__ __forceinline__ float reciprocal_refined(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+
+// The softmax numerator exp(v - max) for a tap volume of type WT (CSPN_ours.py:35).  fp32 weights: the two-piece form above.
+// fp16 weights: one multiply + v_exp_f32 — the argument's error (<= 24 * 1.4e-7 for every result that does not underflow in
+// fp16) moves the numerator by ~2e-6 relative, 200x below half an fp16 ulp, and the derive of the weight-resident K x K
+// launch (cspnk_resident.hip: 24 exponentials per pixel over tile + halo) is VALU-bound on exactly these operations.
+// Every producer of fp16 softmax weights goes through this one function, so they all agree bit for bit.
+template <typename WT> __device__ __forceinline__ float softmax_exp(float d) { return exp_nonpositive(d); }
+template <> __device__ __forceinline__ float softmax_exp<__half>(float d) {
+    return __builtin_amdgcn_exp2f(d * 1.44269502162933349609375f);
+}
+
 // The 10 masked terms of Result.evaluate (libs/metrics.py:49-83) for one pixel, added to f[0..9]:
 // {inv^2, inv, diff^2, diff, diff/t, |log10 o - log10 t|, #(r<1.25), #(r<1.25^2), #(r<1.25^3), 1} over t > 0.
 // Algebraically equal forms that avoid cancellation and redundant divisions:
@@ -235,6 +262,16 @@ __device__ __forceinline__ void load_taps_quad(const __half* img, size_t p, size
 // hoists all of them out of the step loop and materialises the weights as fp32 again (197 instead of ~110 VGPRs).
 __device__ __forceinline__ float fma_packed_tap(const uint4& r, int odd, int e, float x, float acc) {
     const unsigned w = odd ? ((e >> 1) ? r.w : r.z) : ((e >> 1) ? r.y : r.x);
+    float out;
+    if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
+    return out;
+}
+
+// acc + w * x with w = half e (0..7) of an OCT register set: r.x = pixels (0,1), r.y = (2,3), r.z = (4,5), r.w = (6,7) of one
+// tap — the layout of a 16-byte load from a planar fp16 tap / kernel plane.  One v_fma_mix_f32 (see fma_packed_tap).
+__device__ __forceinline__ float fma_h8(const uint4& r, int e, float x, float acc) {
+    const unsigned w = (e >> 1) == 0 ? r.x : ((e >> 1) == 1 ? r.y : ((e >> 1) == 2 ? r.z : r.w));
     float out;
     if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
     else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));

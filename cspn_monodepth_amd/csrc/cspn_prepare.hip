@@ -46,23 +46,6 @@ __global__ void cspn3_prepare_kernel(const GT* __restrict__ g, long bs, long cs,
     }
 }
 
-// exp(x) for x <= 0 (the max-subtracted logits) on the hardware exponential: v_exp_f32 is 2^t to 1 ulp; the product
-// x * log2(e) is formed in two pieces (fma recovers its rounding error) so that the result stays within ~2 ulp of
-// expf for every x instead of drifting by |x| * 2^-24.  libm's expf made both prepare kernels VALU-bound (~25 VALU
-// operations per call, 24 calls per pixel at K = 5: 33.6 us for a pass whose HBM floor is 20 us).
-__device__ __forceinline__ float exp_nonpositive(float x) {
-    const float L2E = 1.44269502162933349609375f;          // float(log2(e))
-    const float L2E_LO = 1.925963033500011e-8f;            // log2(e) - float(log2(e))
-    const float t = x * L2E;
-    const float r = fmaf(x, L2E, -t) + x * L2E_LO;         // what t lost
-    const float e = __builtin_amdgcn_exp2f(t);
-    return fmaf(e, r * 0.693147180559945f, e);             // 2^(t+r) = 2^t (1 + r ln 2 + ...)
-}
-__device__ __forceinline__ float reciprocal_refined(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    return fmaf(fmaf(-d, r, 1.0f), r, r);
-}
-
 // K x K: softmax over the K*K-1 channels at the centre pixel (CSPN_ours.py:35); tap j = channel j.
 template <int K, typename GT, typename WT>
 __global__ void cspn_pac_prepare_kernel(const GT* __restrict__ g, int B, int H, int W, WT* __restrict__ wk) {
@@ -79,7 +62,7 @@ __global__ void cspn_pac_prepare_kernel(const GT* __restrict__ g, int B, int H, 
         for (int c = 0; c < NT; ++c) { v[c] = ld1(gb + (size_t)c * HW); mx = fmaxf(mx, v[c]); }
         float den = 0.f;
 #pragma unroll
-        for (int c = 0; c < NT; ++c) { v[c] = exp_nonpositive(v[c] - mx); den += v[c]; }
+        for (int c = 0; c < NT; ++c) { v[c] = softmax_exp<WT>(v[c] - mx); den += v[c]; }
         // one reciprocal + NT multiplies instead of NT divisions (the pass is VALU-bound); den >= 1 unless NaN
         const float inv = reciprocal_refined(den);
 #pragma unroll
@@ -111,7 +94,7 @@ __global__ __launch_bounds__(256) void cspn_pac_prepare_vec_kernel(const GT* __r
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[c][e] = exp_nonpositive(v[c][e] - mx[e]); den[e] += v[c][e]; }
+            for (int e = 0; e < 4; ++e) { v[c][e] = softmax_exp<WT>(v[c][e] - mx[e]); den[e] += v[c][e]; }
         float inv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) inv[e] = reciprocal_refined(den[e]);

@@ -49,7 +49,9 @@ struct ResArgs {
     float* xbuf;             // exchange planes [2][B,H,W] (workspace)
     unsigned* flags;         // [B * tiles_per_img] phase flags (workspace, zero-initialised once)
     unsigned* status;        // [0] abort word of the running launch chain, [1] sticky error word (workspace)
-    unsigned* host_err;      // optional host-mapped word that receives the error as well
+    unsigned* host_err;      // optional TWO host-mapped words: [0] receives the error as well, [1] receives `seq` when the
+                             // last launch of the call has finished (all workgroups passed their end)
+    int last_chunk;          // this launch is the last one of the call
     unsigned seq;            // flag base of this call: a tile that finished phase p publishes seq + p + 1
     float* hist;             // MODE 2: [T][B,H,W] receives the state after every step (d_1 .. d_T), `out` is unused
     float* w_out;            // MODE 2: [B,8,H,W] receives the normalised weights (the backward streams them)
@@ -146,6 +148,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     int n_stamp = 0;
     auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
     stamp();
+    // Completion word: every workgroup counts itself out (status word 2); the last one re-arms the counter for the next
+    // launch — launches on a workspace never overlap — and, in the last launch of a call, stores `seq` to the second host
+    // word.  A host that polls that word (no HIP call, no event on the stream) knows the call has finished and that
+    // host_err[0] is final: a workgroup that gave up stored the error, fenced at system scope, and only then counted out.
+    auto count_out = [&]() {
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == gridDim.x) {
+                __hip_atomic_store(a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.host_err && a.last_chunk) __hip_atomic_store(a.host_err + 1, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
 
     const float* __restrict__ din0 = uniform_ptr(a.d0 + (size_t)b * HW);
     const float* __restrict__ spg = BLEND ? uniform_ptr(a.sparse + (size_t)b * HW) : nullptr;
@@ -632,6 +647,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 if (tid == 0) {
                     __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __atomic_thread_fence(__ATOMIC_SEQ_CST);       // the error is visible to the host before this tile counts out
                 }
                 // Poison what this tile will never produce: its part of the refined depth (or of the last history plane —
                 // d_T in the training forward, G_0 in the reverse sweep) becomes NaN, so that a result consumed before the
@@ -645,6 +661,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     for (int i = 0; i < NQ; ++i)
                         if ((interior >> i) & 1u) st4(at32(pz, o0 + (unsigned)(i * W)), make_float4(qnan, qnan, qnan, qnan));
                 }
+                count_out();
                 return;
             }
         }
@@ -689,6 +706,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + tid, v);
         }
     }
+    count_out();
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -952,6 +970,7 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
+        a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
         switch (g.nq) {

@@ -1,0 +1,850 @@
+// cspnk_resident.hip — the K x K softmax (pixel-adaptive) propagation as weight-RESIDENT launches: fp16 taps in registers.
+//
+// Reference path: network/libs/post_process/CSPN_ours.py:24-54 (softmax over the K*K-1 guidance channels :35, zero centre
+// tap :37-39, prop_time x { pac.conv2d :49, sparse blend :51-53 }) with network/libs/base/pac.py:89-92 as the step.
+// BASELINE config 3: K = 5, 12 steps, fp16, B = 24 at 228x304.  The multi-launch schedule (cspn_pac_prepare + three S = 4
+// launches of cspn_prop_fused + cspn_metrics) moves 429 MB per forward against 90 MB compulsory: the softmax writes an
+// 80 MB tap volume that every launch streams again.  Here a workgroup owns ONE tile for the whole forward:
+//   * it derives the softmax weights of its tile + halo from the raw fp16 guidance ONCE — same arithmetic as
+//     cspn_pac_prepare_vec_kernel (softmax_exp<__half>, reciprocal_refined, round-to-nearest-even to fp16), so the taps are
+//     bit-identical to the prepared volume's — and keeps them PACKED in VGPRs: a thread owns NO horizontally aligned
+//     OCTS (8 pixels of one row: one 16-byte load per guidance channel), K*K-1 taps x 4 registers per oct, fed to
+//     v_fma_mix_f32 through its op_sel bits (fma_h8).  No tap volume exists;
+//   * the T steps run in phases of S steps on the fp32 depth tile in LDS, rows stored as two arrays of quads (even / odd
+//     quads of the row) so that an oct is two conflict-free ds_read_b128 and the R-pixel halo columns are two ds_read_b64
+//     of the neighbouring octs: no DPP, no divergent patch blocks (the step is VALU-bound on its 8 (K*K-1) FMAs per oct);
+//   * between phases the tiles exchange borders through a global plane with device-scope (sc1) stores / loads and per-tile
+//     phase flags, exactly as cspn3_resident (cspn_resident.hip) — same workspace layout, same bounded wait, same sticky
+//     error + completion words.
+// State dtype: the depth planes (x0, sparse, out, target, exchange) are fp16 or fp32.  With fp16 state the multi-launch
+// schedule rounds the state to half between launches; the resident launch rounds it at the phase boundaries, so with
+// steps_per_phase = steps_per_launch the two schedules produce the same bits (tests/test_hip_kres.py).
+//
+// Register budget: 24 taps x 4 = 96 VGPRs per oct; NO = 2 at 512 threads (2 wavefronts per SIMD, 256 VGPRs).  The tap volume of
+// config 3 (80 MB) does not fit the chip's register files with its halo (131 MB in all), so the batch goes through two
+// launches of 12 images (20 tiles each); see DESIGN.md §4.1c for the arithmetic.
+#include "cspn_common.hpp"
+
+#include <atomic>
+
+namespace {
+
+struct KResArgs {
+    const __half* g;         // guided [B, K*K-1, H, W] f16
+    const void* x0;          // [B,H,W] ST: the coarse depth
+    const void* sparse;      // [B,H,W] ST or null
+    void* out;               // [B,H,W] ST
+    void* xbuf;              // exchange planes [2][B,H,W] ST (workspace)
+    unsigned* flags;         // [B * tiles_per_img] phase flags
+    unsigned* status;        // [0] abort, [1] sticky error, [2] count-out counter
+    unsigned* host_err;      // optional two host-mapped words (error, completion: include/cspn_hip.h)
+    unsigned seq;
+    const void* target;      // SCORE: [B,H,W] ST
+    double* macc;
+    int nslots;
+    int B, H, W, T, S;
+    int tw, th, tiles_x, tiles_y;
+    int wo, wr, hxw, hyw, dr, ls;
+    int b0, nb, last_chunk;
+    unsigned spin_limit;
+};
+
+#define GLB __attribute__((address_space(1)))
+typedef GLB char* gptr;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) v2f* lds_cv2f_ptr;
+typedef const volatile __attribute__((address_space(3))) float* lds_cf_ptr;
+
+template <typename T>
+__device__ __forceinline__ T* kuniform_ptr(T* p) {      // a wave-uniform pointer, pinned to an SGPR pair
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// SGPR base + 32-bit BYTE offset, typed as a global (address space 1) pointer: no 64-bit address arithmetic, no flat loads
+__device__ __forceinline__ gptr atb(const void* base, unsigned byte_off) {
+    return (gptr) reinterpret_cast<unsigned long long>(base) + byte_off;
+}
+__device__ __forceinline__ uint4 ld16(gptr p) {
+    const v4u v = *reinterpret_cast<const GLB v4u*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st16(gptr p, uint4 v) {
+    const v4u w = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<GLB v4u*>(p) = w;
+}
+__device__ __forceinline__ unsigned ld4u(gptr p) { return *reinterpret_cast<const GLB unsigned*>(p); }
+__device__ __forceinline__ uint2 ld8u(gptr p) {
+    const v2u v = *reinterpret_cast<const GLB v2u*>(p);
+    return make_uint2(v.x, v.y);
+}
+// device-scope (sc1) accesses: coherent across the XCDs' private L2s without cache-wide write-back / invalidate
+__device__ __forceinline__ uint4 ld16_dev(gptr p) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+}
+__device__ __forceinline__ uint2 ld8u_dev(gptr p) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)lo, (unsigned)(lo >> 32));
+}
+__device__ __forceinline__ unsigned ld4u_dev(gptr p) {
+    return __hip_atomic_load(reinterpret_cast<const GLB unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st16_dev(const void* base, unsigned byte_off, uint4 v) {
+    // ONE 16-byte device-scope store (the compiler only offers <= 8-byte atomics; two of them touch every line twice)
+    const v4u w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(w), "s"(base) : "memory");
+}
+
+__device__ __forceinline__ float h2f_lo(unsigned w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xffffu))); }
+__device__ __forceinline__ float h2f_hi(unsigned w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
+__device__ __forceinline__ unsigned f2h_bits(float v) { return (unsigned)__half_as_ushort(__float2half_rn(v)); }
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) { return f2h_bits(lo) | (f2h_bits(hi) << 16); }
+
+// The depth planes of a call are fp16 or fp32: an OCT (8 pixels of a row) is one or two 16-byte accesses, a PAIR (the two
+// ring pixels left / right of a region row) one 4- or 8-byte access.
+template <typename ST> struct StateIO;
+template <> struct StateIO<__half> {
+    struct Oct { uint4 a; };
+    struct Pair { unsigned a; };
+    static __device__ __forceinline__ Oct ld_oct(const void* b, unsigned e) { return Oct{ld16(atb(b, e * 2u))}; }
+    static __device__ __forceinline__ Oct ld_oct_dev(const void* b, unsigned e) { return Oct{ld16_dev(atb(b, e * 2u))}; }
+    static __device__ __forceinline__ Pair ld_pair(const void* b, unsigned e) { return Pair{ld4u(atb(b, e * 2u))}; }
+    static __device__ __forceinline__ Pair ld_pair_dev(const void* b, unsigned e) { return Pair{ld4u_dev(atb(b, e * 2u))}; }
+    static __device__ __forceinline__ void to_f8(const Oct& o, float (&v)[8]) {
+        v[0] = h2f_lo(o.a.x); v[1] = h2f_hi(o.a.x); v[2] = h2f_lo(o.a.y); v[3] = h2f_hi(o.a.y);
+        v[4] = h2f_lo(o.a.z); v[5] = h2f_hi(o.a.z); v[6] = h2f_lo(o.a.w); v[7] = h2f_hi(o.a.w);
+    }
+    static __device__ __forceinline__ void to_f2(const Pair& p, float& a, float& b) { a = h2f_lo(p.a); b = h2f_hi(p.a); }
+    static __device__ __forceinline__ Oct from_f8(const float (&v)[8]) {
+        return Oct{make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]))};
+    }
+    static __device__ __forceinline__ void st_oct(void* b, unsigned e, const Oct& o) { st16(atb(b, e * 2u), o.a); }
+    static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 2u, o.a); }
+};
+template <> struct StateIO<float> {
+    struct Oct { uint4 a, b; };
+    struct Pair { uint2 a; };
+    static __device__ __forceinline__ Oct ld_oct(const void* b, unsigned e) { return Oct{ld16(atb(b, e * 4u)), ld16(atb(b, e * 4u + 16u))}; }
+    static __device__ __forceinline__ Oct ld_oct_dev(const void* b, unsigned e) { return Oct{ld16_dev(atb(b, e * 4u)), ld16_dev(atb(b, e * 4u + 16u))}; }
+    static __device__ __forceinline__ Pair ld_pair(const void* b, unsigned e) { return Pair{ld8u(atb(b, e * 4u))}; }
+    static __device__ __forceinline__ Pair ld_pair_dev(const void* b, unsigned e) { return Pair{ld8u_dev(atb(b, e * 4u))}; }
+    static __device__ __forceinline__ void to_f8(const Oct& o, float (&v)[8]) {
+        v[0] = __uint_as_float(o.a.x); v[1] = __uint_as_float(o.a.y); v[2] = __uint_as_float(o.a.z); v[3] = __uint_as_float(o.a.w);
+        v[4] = __uint_as_float(o.b.x); v[5] = __uint_as_float(o.b.y); v[6] = __uint_as_float(o.b.z); v[7] = __uint_as_float(o.b.w);
+    }
+    static __device__ __forceinline__ void to_f2(const Pair& p, float& a, float& b) { a = __uint_as_float(p.a.x); b = __uint_as_float(p.a.y); }
+    static __device__ __forceinline__ Oct from_f8(const float (&v)[8]) {
+        return Oct{make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])),
+                   make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]))};
+    }
+    static __device__ __forceinline__ void st_oct(void* b, unsigned e, const Oct& o) { st16(atb(b, e * 4u), o.a); st16(atb(b, e * 4u + 16u), o.b); }
+    static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 4u, o.a); st16_dev(b, e * 4u + 16u, o.b); }
+};
+
+__device__ __forceinline__ unsigned& comp(uint4& r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); }
+
+constexpr int KRES_THREADS = 512;
+
+// LDS layout of one depth buffer: dr rows of `ls` floats; a row holds the EVEN quads of its octs, E[k+1] = pixels 0..3 of oct k
+// (k = -1 .. wo: one ring oct on each side), then the ODD quads O[k+1] = pixels 4..7, each array (wo + 2) quads long.  Thread
+// (sy, sx) reads E[sx], O[sx] with ds_read_b128 (consecutive lanes = consecutive 16-byte slots: conflict-free) and the R
+// pixels left / right of its oct as the tail of O[sx-1] / the head of E[sx+1].
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST>
+__global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs a) {
+    constexpr int R = K / 2, NT = K * K - 1, NTH = KRES_THREADS;
+    static_assert(R == 1 || R == 2, "K = 3 or 5");
+    using IO = StateIO<ST>;
+    using Oct = typename IO::Oct;
+    using Pair = typename IO::Pair;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int wg_bad;
+
+    const int tid = threadIdx.x;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int tile = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int bl = tile / tiles_per_img;
+    const int trem = tile - bl * tiles_per_img;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int b = a.b0 + bl;
+    const int H = a.H, W = a.W;
+    const int y0 = ty * a.th, x0 = tx * a.tw;
+    const unsigned HW = (unsigned)(H * W);
+    const size_t plane = (size_t)a.B * HW;
+    if (tid == 0) wg_bad = 0;
+    auto count_out = [&]() {                       // see cspn3_resident: completion word for host-side polling
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == gridDim.x) {
+                __hip_atomic_store(a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.host_err && a.last_chunk) __hip_atomic_store(a.host_err + 1, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+
+    const ST* __restrict__ x0b = kuniform_ptr(static_cast<const ST*>(a.x0) + (size_t)b * HW);
+    const ST* __restrict__ spb = BLEND ? kuniform_ptr(static_cast<const ST*>(a.sparse) + (size_t)b * HW) : nullptr;
+
+    // ---- ownership: strip (sx, sy) = NO vertically consecutive octs of the weight region (tile + halo) ----------------
+    const int wo = a.wo, wr = a.wr;
+    const int sy = tid / wo;
+    const int sx = tid - sy * wo;
+    const int r0 = sy * NO;
+    // region origin, shifted back into the image at image edges (cspn3_resident: never before the previous tile's start, so
+    // that the halo always comes from the 8 adjacent tiles)
+    const int rx0 = max(max(0, x0 - a.tw), min(x0 - a.hxw, W - 8 * wo));
+    const int ry0 = max(max(0, y0 - a.th), min(y0 - a.hyw, H - wr));
+    const int xo = rx0 + 8 * sx;
+    const int yo0 = ry0 + r0;
+    const bool x_in = xo < W;                  // W % 8 == 0: an oct lies inside the image or outside as a whole
+
+    // ---- 0. the depth region of phase 0 is requested FIRST (loads return in order: it is parked in LDS while the guidance
+    //         stream is still in flight)
+    const int dr = a.dr, ls = a.ls;
+    const int pp = dr * ls;                    // floats per depth buffer
+    float* const cur = lds;                    // buffer 0: where every phase starts (phases have an even number of steps)
+    float* const nxt = lds + pp;
+    const int yd0 = ry0 - R;
+    const int eo = 4 * (wo + 2);               // offset of the odd-quad array inside a row
+    Oct st0[NO + 1];                           // dr * wo <= (NO + 1) * NTH octs (the host checks)
+    unsigned st0_in = 0;
+    const int step_r = NTH / wo, step_q = NTH - step_r * wo;
+    {
+        int row = sy, oc = sx;
+#pragma unroll
+        for (int u = 0; u <= NO; ++u) {
+            const int y = yd0 + row, x = rx0 + 8 * oc;
+            const bool in = (row < dr) && y >= 0 && y < H && x < W;
+            if (in) st0_in |= 1u << u;
+            st0[u] = IO::ld_oct(x0b, in ? (unsigned)(y * W + x) : 0u);
+            row += step_r; oc += step_q;
+            if (oc >= wo) { oc -= wo; ++row; }
+        }
+    }
+    // the R-pixel ring left / right of the region rows: one pair (R = 2) or one pixel (R = 1, read as the pair it sits in)
+    // per row and side; 2 * dr <= 2 * NTH items
+    Pair rg[2];
+    unsigned rg_in = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int t = tid + k * NTH;
+        const int row = t >> 1, side = t & 1;
+        const int y = yd0 + row, x = side ? rx0 + 8 * wo : rx0 - 2;
+        const bool in = (t < 2 * dr) && y >= 0 && y < H && x >= 0 && x < W;
+        if (in) rg_in |= 1u << k;
+        rg[k] = IO::ld_pair(x0b, in ? (unsigned)(y * W + x) : 0u);
+    }
+
+    // ---- 1. guidance of the owned octs: NT 16-byte loads per oct, all requested before the arithmetic ------------------
+    uint4 wpk[NO][NT];
+    unsigned in_img = 0, interior = 0;
+    const __half* __restrict__ gb = kuniform_ptr(a.g + (size_t)b * NT * HW);
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+        const int y = yo0 + i;
+        const bool ok = (r0 + i < wr) && x_in && y < H;
+        if (ok) in_img |= 1u << i;
+        if (ok && y >= y0 && y < y0 + a.th && xo >= x0 && xo < x0 + a.tw) interior |= 1u << i;
+        const unsigned off = ok ? (unsigned)(y * W + xo) : 0u;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wpk[i][c] = ld16(atb(gb, ((unsigned)c * HW + off) * 2u));
+    }
+
+    // ---- park the depth region (its loads came first: only those are waited for here) ---------------------------------
+    {
+        int tidk = tid, prow = sy, poc = sx;
+        asm volatile("" : "+v"(tidk), "+v"(prow), "+v"(poc));
+#pragma unroll
+        for (int u = 0; u <= NO; ++u) {
+            float v[8];
+            IO::to_f8(st0[u], v);
+            const bool in = (st0_in >> u) & 1u;
+            if (prow < dr) {
+                float* p = cur + prow * ls + 4 * (poc + 1);
+                *reinterpret_cast<float4*>(p) = make_float4(in ? v[0] : 0.f, in ? v[1] : 0.f, in ? v[2] : 0.f, in ? v[3] : 0.f);
+                *reinterpret_cast<float4*>(p + eo) = make_float4(in ? v[4] : 0.f, in ? v[5] : 0.f, in ? v[6] : 0.f, in ? v[7] : 0.f);
+            }
+            prow += step_r; poc += step_q;
+            if (poc >= wo) { poc -= wo; ++prow; }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = tidk + k * NTH;
+            if (t < 2 * dr) {
+                const int row = t >> 1, side = t & 1;
+                float p0, p1;
+                IO::to_f2(rg[k], p0, p1);
+                const bool in = (rg_in >> k) & 1u;
+                const int at = row * ls + (side ? 4 * (wo + 1) : eo + 2);     // E[wo].xy  /  O[-1].zw
+                cur[at] = in ? p0 : 0.f; cur[at + 1] = in ? p1 : 0.f;
+                nxt[at] = 0.f; nxt[at + 1] = 0.f;       // the ring of the second buffer is never computed: it must read as 0
+            }
+        }
+        // ... and so must its ring ROWS (with shifted regions they are the zero padding above / below the image)
+        for (int c = tidk; c < 2 * R * ls; c += NTH) {
+            const int rr = c / ls, col = c - rr * ls;
+            nxt[(rr < R ? rr : dr - 2 * R + rr) * ls + col] = 0.f;
+        }
+    }
+
+    // ---- 2. softmax over the NT channels of every owned pixel, in place: raw halfs -> fp16 weights ----------------------
+    // (CSPN_ours.py:35; the arithmetic of cspn_pac_prepare_vec_kernel: max, softmax_exp<__half>, sum in channel order,
+    // one refined reciprocal, round to nearest even.)  One pixel at a time: 24 temporaries next to the 96 * NO tap registers.
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float v[NT];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const unsigned w = comp(wpk[i][c], q);
+                    v[c] = hf ? h2f_hi(w) : h2f_lo(w);
+                    mx = fmaxf(mx, v[c]);
+                }
+                float den = 0.f;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) { v[c] = softmax_exp<__half>(v[c] - mx); den += v[c]; }
+                const float inv = reciprocal_refined(den);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const unsigned hb = f2h_bits(v[c] * inv);
+                    unsigned& w = comp(wpk[i][c], q);
+                    w = hf ? ((w & 0xffffu) | (hb << 16)) : ((w & 0xffff0000u) | hb);
+                }
+            }
+        }
+    }
+
+    // ---- sparse blend operands of the owned octs: om = 1 - m, md = m * x0 (m = sign(sparse)), private LDS slots ----------
+    float* const om_lds = lds + 2 * pp;
+    float* const md_lds = om_lds + wr * wo * 8;
+    if (BLEND) {
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+            if (r0 + i < wr) {
+                const bool ok = (in_img >> i) & 1u;
+                const unsigned off = ok ? (unsigned)((yo0 + i) * W + xo) : 0u;
+                float sp[8], dv[8];
+                IO::to_f8(IO::ld_oct(spb, off), sp);
+                IO::to_f8(IO::ld_oct(x0b, off), dv);
+                float om[8], md[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float m = ok ? sgnf(sp[e]) : 0.f;
+                    om[e] = 1.f - m;
+                    md[e] = m * (ok ? dv[e] : 0.f);
+                }
+                float* po = om_lds + ((r0 + i) * wo + sx) * 8;
+                float* pm = md_lds + ((r0 + i) * wo + sx) * 8;
+                *reinterpret_cast<float4*>(po) = make_float4(om[0], om[1], om[2], om[3]);
+                *reinterpret_cast<float4*>(po + 4) = make_float4(om[4], om[5], om[6], om[7]);
+                *reinterpret_cast<float4*>(pm) = make_float4(md[0], md[1], md[2], md[3]);
+                *reinterpret_cast<float4*>(pm + 4) = make_float4(md[4], md[5], md[6], md[7]);
+            }
+        }
+    }
+
+    // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes ----------------------
+    const bool active = r0 < wr;
+    ST* __restrict__ outb = kuniform_ptr(static_cast<ST*>(a.out) + (size_t)b * HW);
+    const int n_phase = (a.T + a.S - 1) / a.S;
+    const int tile_global = b * tiles_per_img + trem;
+    int fin_buf = 0;                           // LDS buffer that receives the final step's (stored) values: the fused metrics read them back
+
+    for (int p = 0; p < n_phase; ++p) {
+        const int steps = (a.T - p * a.S) < a.S ? (a.T - p * a.S) : a.S;
+        const bool last_phase = (p == n_phase - 1);
+        ST* __restrict__ xout = kuniform_ptr(static_cast<ST*>(a.xbuf) + (size_t)(p & 1) * plane + (size_t)b * HW);
+        if (p > 0) {
+            // halo octs only (the tile's own interior is in LDS already): full rows above and below the tile rows, the octs
+            // left and right of the tile columns; device-scope loads, two per thread and trip, requested before they are used
+            const ST* __restrict__ xin = kuniform_ptr(static_cast<const ST*>(a.xbuf) + (size_t)((p + 1) & 1) * plane + (size_t)b * HW);
+            const int tq_in = min(a.tw, rx0 + 8 * wo - x0) >> 3;
+            const int th_in = min(a.th, ry0 + wr - y0);
+            const int nl = (x0 - rx0) >> 3;
+            const int nside = wo - tq_in;
+            const int nrow_t = (y0 - ry0) + R;
+            const int n_top = nrow_t * wo;
+            const int n_bot = (dr - nrow_t - th_in) * wo;
+            const int n_halo = n_top + n_bot + th_in * nside;
+            Pair rgp[2];
+            unsigned rgp_in = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = tid + k * NTH;
+                const int row = t >> 1, side = t & 1;
+                const int y = yd0 + row, x = side ? rx0 + 8 * wo : rx0 - 2;
+                const bool in = (t < 2 * dr) && y >= 0 && y < H && x >= 0 && x < W;
+                if (in) rgp_in |= 1u << k;
+                rgp[k] = IO::ld_pair_dev(xin, in ? (unsigned)(y * W + x) : 0u);
+            }
+            for (int base = 0; base < n_halo; base += 2 * NTH) {
+                Oct hv[2];
+                int at[2];
+                bool hin[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int h = base + u * NTH + tid;
+                    int row, oc;
+                    if (h < n_top) { row = h / wo; oc = h - row * wo; }
+                    else if (h < n_top + n_bot) { const int h2 = h - n_top; row = h2 / wo; oc = h2 - row * wo; row += nrow_t + th_in; }
+                    else {
+                        const int h3 = h - n_top - n_bot;
+                        const int ns = nside > 0 ? nside : 1;
+                        row = h3 / ns;
+                        const int c = h3 - row * ns;
+                        row += nrow_t;
+                        oc = c < nl ? c : c + tq_in;
+                    }
+                    const int y = yd0 + row, x = rx0 + 8 * oc;
+                    const bool valid = h < n_halo;
+                    hin[u] = valid && y >= 0 && y < H && x < W;
+                    hv[u] = IO::ld_oct_dev(xin, hin[u] ? (unsigned)(y * W + x) : 0u);
+                    at[u] = valid ? row * ls + 4 * (oc + 1) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (at[u] >= 0) {
+                        float v[8];
+                        IO::to_f8(hv[u], v);
+                        const bool in = hin[u];
+                        *reinterpret_cast<float4*>(cur + at[u]) = make_float4(in ? v[0] : 0.f, in ? v[1] : 0.f, in ? v[2] : 0.f, in ? v[3] : 0.f);
+                        *reinterpret_cast<float4*>(cur + at[u] + eo) = make_float4(in ? v[4] : 0.f, in ? v[5] : 0.f, in ? v[6] : 0.f, in ? v[7] : 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = tid + k * NTH;
+                if (t < 2 * dr) {
+                    const int row = t >> 1, side = t & 1;
+                    float p0, p1;
+                    IO::to_f2(rgp[k], p0, p1);
+                    const bool in = (rgp_in >> k) & 1u;
+                    const int at = row * ls + (side ? 4 * (wo + 1) : eo + 2);
+                    cur[at] = in ? p0 : 0.f; cur[at + 1] = in ? p1 : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+
+        // One propagation step on the LDS tile: kind 0 = plain, 1 = last step of a phase (the interior is published, the
+        // state rounded to the plane dtype first), 2 = the final step of the forward (refined depth stored, kept for scoring).
+        auto step = [&](const int kind, const float* rd, float* wrb) __attribute__((always_inline)) {
+            float acc[NO][8];
+#pragma unroll
+            for (int i = 0; i < NO; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < NO + 2 * R; ++rr) {
+                int drow = r0 + rr;                      // depth-region row of window row rr; rows past the region (idle
+                drow = drow < dr ? drow : dr - 1;        // octs of the last strip) read the clamped last row, never stored
+                const float* rowp = rd + drow * ls + 4 * (sx + 1);
+                float x[8 + 2 * R];
+                const v4f e4 = *(lds_cv4f_ptr)(rowp);
+                const v4f o4 = *(lds_cv4f_ptr)(rowp + eo);
+                x[R + 0] = e4.x; x[R + 1] = e4.y; x[R + 2] = e4.z; x[R + 3] = e4.w;
+                x[R + 4] = o4.x; x[R + 5] = o4.y; x[R + 6] = o4.z; x[R + 7] = o4.w;
+                if constexpr (R == 2) {
+                    const v2f l2 = *(lds_cv2f_ptr)(rowp + eo - 2);          // O[sx-1].zw
+                    const v2f r2 = *(lds_cv2f_ptr)(rowp + 4);               // E[sx+1].xy
+                    x[0] = l2.x; x[1] = l2.y; x[10] = r2.x; x[11] = r2.y;
+                } else {
+                    x[0] = *(lds_cf_ptr)(rowp + eo - 1);                    // O[sx-1].w
+                    x[9] = *(lds_cf_ptr)(rowp + 4);                         // E[sx+1].x
+                }
+#pragma unroll
+                for (int i = 0; i < NO; ++i) {
+                    const int dy = rr - R - i;
+                    if (dy < -R || dy > R) continue;
+#pragma unroll
+                    for (int dx = -R; dx <= R; ++dx) {
+                        if (dy == 0 && dx == 0) continue;
+                        const int lin = (dy + R) * K + (dx + R);
+                        const int j = lin < (K * K) / 2 ? lin : lin - 1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][e] = fma_h8(wpk[i][j], e, x[R + e + dx], acc[i][e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = acc[i][e];
+                if (BLEND) {
+                    const int q = (min(r0 + i, wr - 1) * wo + sx) * 8;
+                    const float4 oa = *reinterpret_cast<const float4*>(om_lds + q), ob = *reinterpret_cast<const float4*>(om_lds + q + 4);
+                    const float4 ma = *reinterpret_cast<const float4*>(md_lds + q), mb = *reinterpret_cast<const float4*>(md_lds + q + 4);
+                    const float om[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+                    const float md[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = om[e] * u[e] + md[e];       // (1-m) u + m x0   CSPN_ours.py:51-53
+                }
+                if (!CLEAN) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = ((in_img >> i) & 1u) ? u[e] : 0.f;   // zero padding stays exactly zero
+                }
+                const bool inner = (interior >> i) & 1u;
+                const unsigned off = (unsigned)((yo0 + i) * W + xo);
+                if (kind != 0) {                         // the state leaves the launch in the plane dtype
+                    const Oct o = IO::from_f8(u);
+                    if (sizeof(ST) == 2) IO::to_f8(o, u);
+                    if (kind == 1) { if (inner) IO::st_oct_dev(xout, off, o); }
+                    else if (inner) IO::st_oct(outb, off, o);
+                }
+                // (the final step writes LDS too when the metrics are fused: they score the stored values, read back from the
+                // thread's own slots after the loop — sixteen registers carried out of the step cost the hot loop its spill-free form)
+                if ((kind != 2 || SCORE) && r0 + i < wr) {
+                    float* p = wrb + (r0 + i + R) * ls + 4 * (sx + 1);
+                    *reinterpret_cast<float4*>(p) = make_float4(u[0], u[1], u[2], u[3]);
+                    *reinterpret_cast<float4*>(p + eo) = make_float4(u[4], u[5], u[6], u[7]);
+                }
+            }
+        };
+        const bool any = __ballot(active) != 0ull;          // wavefronts without a single owned row only keep the barriers company
+        for (int s = 0; s < steps; ++s) {
+            const int kind = (s == steps - 1) ? (last_phase ? 2 : 1) : 0;
+            if (any) step(kind, lds + (s & 1) * pp, lds + ((s + 1) & 1) * pp);
+            if (kind == 2) fin_buf = (s + 1) & 1;
+            if (kind == 0) __syncthreads();
+        }
+        if (!last_phase) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's device-scope stores have landed
+            __syncthreads();                                       // ... and so have everybody else's in the workgroup
+            const unsigned want = a.seq + (unsigned)p + 1u;
+            if (tid == 0) __hip_atomic_store(a.flags + tile_global, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 9 && tid != 4) {
+                const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
+                    const unsigned* f = a.flags + b * tiles_per_img + ny * a.tiles_x + nx;
+                    unsigned spins = 0;
+                    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                        ++spins;
+                        if ((spins & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
+                            wg_bad = 1;
+                            break;
+                        }
+                        if (spins > a.spin_limit) {                // a neighbour never became resident / finished: give up
+                            __hip_atomic_store(a.status, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            wg_bad = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+            __syncthreads();
+            if (wg_bad) {
+                if (tid == 0) {
+                    __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                }
+                // poison what this tile will never produce (NaN in the plane dtype), as cspn3_resident does
+                float qn[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qn[e] = __uint_as_float(0x7fc00000u);
+                const Oct o = IO::from_f8(qn);
+#pragma unroll
+                for (int i = 0; i < NO; ++i)
+                    if ((interior >> i) & 1u) IO::st_oct(outb, (unsigned)((yo0 + i) * W + xo), o);
+                count_out();
+                return;
+            }
+        }
+    }
+    if (SCORE) {
+        float mf[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) mf[k] = 0.f;
+        if (active) {
+            const ST* tgt_b = kuniform_ptr(static_cast<const ST*>(a.target) + (size_t)b * HW);
+            Oct tq[NO];
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const bool in = (interior >> i) & 1u;
+                tq[i] = IO::ld_oct(tgt_b, in ? (unsigned)((yo0 + i) * W + xo) : 0u);
+            }
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                if ((interior >> i) & 1u) {
+                    float t8[8];
+                    IO::to_f8(tq[i], t8);
+                    const float* p = lds + fin_buf * pp + (r0 + i + R) * ls + 4 * (sx + 1);
+                    const float4 fa = *reinterpret_cast<const float4*>(p), fb = *reinterpret_cast<const float4*>(p + eo);
+                    const float f8[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) metric_terms(f8[e], t8[e], mf);
+                }
+            }
+        }
+        float* part = lds + 2 * pp + (BLEND ? 2 : 0) * wr * wo * 8;
+        const int wave = tid >> 6, lane = tid & 63;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float v = wave_sum_to_lane63(mf[k]);
+            if (lane == 63) part[wave * 10 + k] = v;
+        }
+        __syncthreads();
+        if (tid < 10) {
+            double v = 0.0;
+            for (int w = 0; w < NTH / 64; ++w) v += (double)part[w * 10 + tid];
+            if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + tid, v);
+        }
+    }
+    count_out();
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+constexpr int KRES_MAX_NO_K5 = 2;
+constexpr int KRES_MAX_NO_K3 = 4;
+
+struct KGeom {
+    int S, tiles_x, tiles_y, tw, th, no, wo, wr, hxw, hyw, dr, ls;
+    int imgs_per_launch, launches;
+    size_t lds_bytes;
+    double cost;
+};
+
+int kcu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cached[dev & 63].store(prop.multiProcessorCount, std::memory_order_relaxed);
+    return prop.multiProcessorCount;
+}
+
+inline int round_up8(int a) { return (a + 7) & ~7; }
+
+// Row stride of a depth buffer: at least the (wo + 2) even and (wo + 2) odd quads, and such that NO * ls = 4 * wo (mod 64
+// dwords) where possible — the 16-byte slot a lane reads is then 4 * tid + const (mod 64): strips stacked in a wavefront
+// continue the bank pattern of the strip before them.
+int kres_row_stride(int wo, int no) {
+    const int lo = 8 * (wo + 2);
+    int best = lo, best_score = 1 << 30;
+    for (int cand = lo; cand < lo + 64; cand += 4) {
+        const int score = (((no * cand - 4 * wo) % 64) + 64) % 64;
+        if (score < best_score) { best_score = score; best = cand; }
+    }
+    return best;
+}
+
+size_t kres_lds_bytes(int dr, int ls, int wr, int wo, int blend) {
+    return ((size_t)2 * dr * ls + (size_t)(blend ? 2 : 0) * wr * wo * 8 + 16 * 10) * sizeof(float);
+}
+
+bool kregions_inside_image(const KGeom& g, int H, int W) {
+    for (int tx = 0; tx < g.tiles_x; ++tx) {
+        const int x0 = tx * g.tw;
+        int rx0 = x0 - g.hxw; if (rx0 > W - 8 * g.wo) rx0 = W - 8 * g.wo;
+        int lo = x0 - g.tw; if (lo < 0) lo = 0;
+        if (rx0 < lo) rx0 = lo;
+        if (rx0 + 8 * g.wo > W) return false;
+    }
+    for (int ty = 0; ty < g.tiles_y; ++ty) {
+        const int y0 = ty * g.th;
+        int ry0 = y0 - g.hyw; if (ry0 > H - g.wr) ry0 = H - g.wr;
+        int lo = y0 - g.th; if (lo < 0) lo = 0;
+        if (ry0 < lo) ry0 = lo;
+        if (ry0 + g.wr > H) return false;
+    }
+    return true;
+}
+
+bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, int tx, int ty, int tw, int th, KGeom* g) {
+    const int R = K / 2;
+    const int max_no = K == 5 ? KRES_MAX_NO_K5 : KRES_MAX_NO_K3;
+    const int hyw = (Se - 1) * R, hxw = round_up8((Se - 1) * R);
+    const int phases = ceil_div(T, Se);
+    if (phases > 1 && (Se & 1)) return false;          // every phase must start in buffer 0
+    if (phases > 255) return false;
+    if ((tw & 7) || tw < 8 || th < 1 || tx * tw < W || ty * th < H) return false;
+    if (phases > 1 && ((tx > 1 && tw < 2 * hxw) || (ty > 1 && th < 2 * hyw))) return false;   // halo from adjacent tiles only
+    const int wo = (tw + 2 * hxw) / 8;
+    if (wo > 128 || wo < 1) return false;
+    const int wr = th + 2 * hyw;
+    const int no = ceil_div(wr, KRES_THREADS / wo);
+    if (no > max_no) return false;
+    const int dr = wr + 2 * R;
+    if (2 * dr > 2 * KRES_THREADS || dr * wo > (no + 1) * KRES_THREADS) return false;
+    const int ls = kres_row_stride(wo, no);
+    const size_t ldsb = kres_lds_bytes(dr, ls, wr, wo, blend);
+    if (ldsb > 160 * 1024) return false;
+    const int tiles = tx * ty;
+    if (tiles > ncu) return false;
+    int ipl = ncu / tiles;
+    if (ipl > B) ipl = B;
+    const int launches = ceil_div(B, ipl);
+    *g = KGeom{Se, tx, ty, tw, th, no, wo, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, 0.0};
+    // microseconds per launch (first fit on MI355X, config 3): launch + epilogue; the derive and a step cost VALU time in
+    // proportion to the octs per thread and the wavefronts per SIMD that own any; each phase boundary a publish / wait /
+    // halo staging round trip
+    const int strips = ceil_div(wr, no) * wo;
+    const int waves_per_simd = ceil_div(ceil_div(strips, 64), 4);
+    const double per_oct = (double)no * waves_per_simd;
+    const double taps = (double)(K * K - 1) / 24.0;
+    const double pen = kregions_inside_image(*g, H, W) ? 1.0 : 1.1;
+    g->cost = launches * (6.0 + 2.7 * taps * per_oct + T * (0.22 * taps * per_oct * pen + 0.08) + (phases - 1) * 4.5);
+    return true;
+}
+
+bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_user, KGeom* best) {
+    if (W % 8 != 0 || ncu < 1 || T < 1 || (K != 3 && K != 5)) return false;
+    bool found = false;
+    const int s_hi = S_user > 0 ? S_user : (K == 3 ? 8 : 6), s_lo = S_user > 0 ? S_user : 2;
+    for (int S = s_hi; S >= s_lo; S -= (S_user > 0 ? 1 : 2)) {
+        const int Se = S > T ? T : S;
+        for (int tx = 1; tx <= 32; ++tx) {
+            const int tw = round_up8(ceil_div(W, tx));
+            if (tx > 1 && (tw < 16 || ceil_div(W, tw) != tx)) continue;
+            for (int ty = 1; ty <= 64; ++ty) {
+                const int th = ceil_div(H, ty);
+                if (ty > 1 && (th < 4 || ceil_div(H, th) != ty)) continue;
+                KGeom cand;
+                if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, tx, ty, tw, th, &cand)) continue;
+                if (!found || cand.cost < best->cost) { found = true; *best = cand; }
+            }
+        }
+    }
+    return found;
+}
+
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST>
+int klaunch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
+    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST>;
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (lds_bytes > 64 * 1024 && granted[dev & 63].load(std::memory_order_acquire) < lds_bytes) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        granted[dev & 63].store(lds_bytes, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KRES_THREADS), lds_bytes, st, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+template <int K, int NO, typename ST>
+int klaunch_no(const KResArgs& a, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
+#define KRES_CASE(BL, SC, CL) \
+    if (blend == BL && score == SC && (int)clean == CL) return klaunch_inst<K, NO, BL, SC, CL, ST>(a, grid, lds, st)
+    KRES_CASE(0, 0, 0); KRES_CASE(0, 0, 1); KRES_CASE(0, 1, 0); KRES_CASE(0, 1, 1);
+    KRES_CASE(1, 0, 0); KRES_CASE(1, 0, 1); KRES_CASE(1, 1, 0); KRES_CASE(1, 1, 1);
+#undef KRES_CASE
+    return fail("cspnk_forward_resident: internal dispatch");
+}
+template <int K, typename ST>
+int klaunch_k(const KResArgs& a, int no, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
+    switch (no) {
+        case 1: return klaunch_no<K, 1, ST>(a, grid, lds, blend, score, clean, st);
+        case 2: return klaunch_no<K, 2, ST>(a, grid, lds, blend, score, clean, st);
+        default: break;
+    }
+    if constexpr (K == 3) {
+        if (no == 3) return klaunch_no<K, 3, ST>(a, grid, lds, blend, score, clean, st);
+        if (no == 4) return klaunch_no<K, 4, ST>(a, grid, lds, blend, score, clean, st);
+    }
+    return fail("cspnk_forward_resident: no instance for K=%d with %d octs per thread", K, no);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cspnk_resident_plan(int K, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* out) {
+    if (!out || B < 1 || H < 1 || W < 1 || T < 0) return fail("cspnk_resident_plan: bad arguments");
+    if (K != 3 && K != 5) return fail("cspnk_resident_plan: K=%d (3 or 5)", K);
+    if (n_cu <= 0) n_cu = kcu_count();
+    if (n_cu <= 0) return fail("cspnk_resident_plan: no device (pass n_cu > 0 to plan without one)");
+    KGeom g;
+    if (T < 1 || !kres_geometry(K, B, H, W, T, blend, n_cu, out->steps_per_phase, &g))
+        return fail("cspnk_resident_plan: no resident tiling for K=%d B=%d %dx%d T=%d on %d CUs (W %% 8 == 0 needed)", K, B, H, W, T, n_cu);
+    out->steps_per_phase = g.S; out->tiles_x = g.tiles_x; out->tiles_y = g.tiles_y; out->tile_w = g.tw; out->tile_h = g.th;
+    out->quads_per_thread = g.no; out->threads = KRES_THREADS; out->images_per_launch = g.imgs_per_launch;
+    out->launches = g.launches; out->lds_bytes = (int)g.lds_bytes; out->n_cu = n_cu;
+    out->region_over_tile = (float)((double)(8 * g.wo) * g.wr / ((double)g.tw * g.th));
+    return 1;
+}
+
+size_t cspnk_resident_workspace_bytes(int B, int H, int W, int state_dtype) {
+    const size_t planes = (size_t)2 * B * H * W * esize(state_dtype);
+    const size_t flags = ((size_t)B * (((size_t)H * W) / 8 + 1) + 4) * sizeof(unsigned);       // tiles are >= 8 x 1
+    return ((planes + 15) & ~(size_t)15) + ((flags + 15) & ~(size_t)15);
+}
+
+int cspnk_forward_resident(const void* guided, int K, const void* x0, const void* sparse, void* out, int state_dtype,
+                           void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend,
+                           const void* target, double* acc, int nslots, const cspn_resident_plan* plan, cspn_stream_t stream) {
+    if (!guided || !x0 || !out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1) return fail("cspnk_forward_resident: bad arguments");
+    if (K != 3 && K != 5) return fail("cspnk_forward_resident: K=%d (3 or 5)", K);
+    if (state_dtype != CSPN_F16 && state_dtype != CSPN_F32) return fail("cspnk_forward_resident: state dtype %d", state_dtype);
+    if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspnk_forward_resident: blend %d", blend);
+    if (blend && !sparse) return fail("cspnk_forward_resident: blend needs sparse");
+    if ((target || acc) && (!target || !acc || nslots < 1)) return fail("cspnk_forward_resident: scoring needs target, acc and nslots >= 1");
+    if (W & 7) return fail("cspnk_forward_resident: W must be a multiple of 8 (whole 16-byte octs of fp16 guidance)");
+    if ((long)(K * K - 1) * H * W >= (1L << 30)) return fail("cspnk_forward_resident: guidance images of >= 2^30 elements are not supported (32-bit offsets)");
+    if (!aligned16(guided) || !aligned16(x0) || !aligned16(out) || !aligned16(work) || (sparse && !aligned16(sparse)) || (target && !aligned16(target)))
+        return fail("cspnk_forward_resident: tensors must be 16-byte aligned");
+    if (seq == 0 || seq > 0x7fffff00u) return fail("cspnk_forward_resident: seq must be in [1, 2^31 - 256]");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ncu = kcu_count();
+    if (ncu <= 0) return fail("cspnk_forward_resident: no device");
+    KGeom g;
+    cspn_resident_plan rp{};
+    if (plan) rp = *plan;
+    if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
+        const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
+        if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, &g) ||
+            (long)rp.images_per_launch * g.tiles_x * g.tiles_y > ncu)
+            return fail("cspnk_forward_resident: the plan does not fit this problem / device (use cspnk_resident_plan)");
+        g.imgs_per_launch = rp.images_per_launch;
+    } else if (!kres_geometry(K, B, H, W, T, blend, ncu, rp.steps_per_phase, &g)) {
+        return fail("cspnk_forward_resident: no resident tiling for K=%d B=%d %dx%d T=%d", K, B, H, W, T);
+    }
+    KResArgs a{};
+    a.g = static_cast<const __half*>(guided); a.x0 = x0; a.sparse = sparse; a.out = out;
+    const size_t planes = (((size_t)2 * B * H * W * esize(state_dtype)) + 15) & ~(size_t)15;
+    a.xbuf = work;
+    a.status = reinterpret_cast<unsigned*>(static_cast<char*>(work) + planes);
+    a.flags = a.status + 4;
+    if ((size_t)g.tiles_x * g.tiles_y > ((size_t)H * W) / 8 + 1) return fail("cspnk_forward_resident: workspace too small for %d tiles per image", g.tiles_x * g.tiles_y);
+    a.host_err = host_err; a.seq = seq;
+    a.target = target; a.macc = acc; a.nslots = nslots;
+    a.B = B; a.H = H; a.W = W; a.T = T; a.S = g.S;
+    a.tw = g.tw; a.th = g.th; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+    a.wo = g.wo; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
+    a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);
+    const bool clean = kregions_inside_image(g, H, W);
+    const int score = acc ? 1 : 0;
+    for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
+        a.b0 = b0;
+        a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
+        a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
+        const int grid = a.nb * g.tiles_x * g.tiles_y;
+        int ok = 0;
+        if (K == 5) {
+            ok = state_dtype == CSPN_F16 ? klaunch_k<5, __half>(a, g.no, grid, g.lds_bytes, blend, score, clean, st)
+                                         : klaunch_k<5, float>(a, g.no, grid, g.lds_bytes, blend, score, clean, st);
+        } else {
+            ok = state_dtype == CSPN_F16 ? klaunch_k<3, __half>(a, g.no, grid, g.lds_bytes, blend, score, clean, st)
+                                         : klaunch_k<3, float>(a, g.no, grid, g.lds_bytes, blend, score, clean, st);
+        }
+        if (!ok) return 0;
+    }
+    return 1;
+}
+
+}  // extern "C"

@@ -339,14 +339,7 @@ __global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T
 // K*K*4 registers, as many as the fp32 quad kernel uses for half the pixels) and feed v_fma_mix_f32 directly (f16 tap
 // x f32 window value + f32 accumulator: the same arithmetic as converting the tap first), the eight results leave as
 // one 16-byte store.  Tile 128 x 16 per workgroup, channels double-buffered through LDS exactly like pac_conv2d_tiled.
-__device__ __forceinline__ float fma_h8(const uint4& r, int e, float x, float acc) {
-    const unsigned w = (e >> 1) == 0 ? r.x : ((e >> 1) == 1 ? r.y : ((e >> 1) == 2 ? r.z : r.w));
-    float out;
-    if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
-    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(x), "v"(acc));
-    return out;
-}
-
+// (fma_h8: cspn_common.hpp)
 constexpr int TILE_W8 = 128;
 
 // HOIST (shared kernel, several channels): all K*K taps are loaded once and stay in registers for every channel.

@@ -10,6 +10,7 @@ import ctypes
 import math
 import os
 import threading
+import time
 
 import torch
 
@@ -651,26 +652,39 @@ def mark_resident_pending(t=None):
 
 
 class _ResidentCheckpoint(object):
-    """An event behind the resident launches issued so far on a device; `wait_and_check` synchronises on it (not on the
-    stream: whatever was enqueued later keeps running) and raises if one of those launches timed out."""
-    __slots__ = ("dev", "event")
+    """A mark behind the resident launches issued so far on a device.  `wait_and_check` waits until the LAST of them has
+    finished and raises if one of them timed out — without a HIP call: the engine's launches store their sequence number
+    to a pinned host word when their last workgroup has counted itself out (include/cspn_hip.h: host_err[1]), so the
+    wait is a poll of host memory; nothing is recorded on the stream and whatever was enqueued later keeps running.
+    (An event + hipEventSynchronize in every backward pass measured +40 us per CSPN forward/backward pair.)"""
+    __slots__ = ("dev", "seq", "stream")
 
     def __init__(self, dev):
         self.dev = dev
         st = _resident_state(dev)
-        cur = torch.cuda.current_stream(dev)
-        last = st["last_stream"]
-        if last is not None and last != cur:
-            cur.wait_stream(last)
-        self.event = torch.cuda.Event()
-        self.event.record(cur)
+        self.seq = st.get("last_seq")
+        self.stream = st["last_stream"]
 
-    def wait_and_check(self):
-        self.event.synchronize()
+    def wait_and_check(self, budget_s=20.0):
+        st = _resident_state(self.dev)
+        if self.seq is not None:
+            words = st["host_err_np"]
+            t_end = None
+            while True:
+                if words[0] != 0:
+                    break
+                if ((int(words[1]) - self.seq) & 0xffffffff) < 0x80000000:      # done word has reached (or passed) this call
+                    break
+                if t_end is None:
+                    t_end = time.perf_counter() + budget_s
+                elif time.perf_counter() > t_end:        # a graph replay or a sequence wrap in between: wait the plain way
+                    if self.stream is not None:
+                        self.stream.synchronize()
+                    break
         check_resident_errors(self.dev)
 
 
-def _resident_launch(dev, B, H, W, T, launch):
+def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None):
     """The host protocol of every resident launch on `dev`: one at a time per device (lock; a launch from another stream
     first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence number,
     the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call.
@@ -685,10 +699,12 @@ def _resident_launch(dev, B, H, W, T, launch):
     log = _EVENT_LOG
     if log is not None and not log.take():
         log = None
+    if ws_bytes_fn is None:
+        ws_bytes_fn = lambda: L.cspn3_resident_workspace_bytes(B, H, W)      # noqa: E731
     if torch.cuda.is_current_stream_capturing():
-        nbytes = L.cspn3_resident_workspace_bytes(B, H, W)
+        nbytes = ws_bytes_fn()
         work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        work[(2 * B * H * W * 4 + 15) & ~15:].zero_()
+        work[(2 * B * H * W * state_bytes + 15) & ~15:].zero_()
         st = _resident_state(dev)
         with _device_guard(dev):
             cur = torch.cuda.current_stream(dev)
@@ -697,12 +713,12 @@ def _resident_launch(dev, B, H, W, T, launch):
         st = _resident_state(dev)
         if st["host_err_np"][0] != 0:
             check_resident_errors(dev)                  # raises
-        key = (B, H, W)
+        key = (B, H, W, ws_kind, state_bytes)
         work = st["work"].get(key)
         if work is None:
             if len(st["work"]) > 16:
                 st["work"].clear()
-            work = st["work"][key] = torch.zeros((L.cspn3_resident_workspace_bytes(B, H, W),), dtype=torch.uint8, device=dev)
+            work = st["work"][key] = torch.zeros((ws_bytes_fn(),), dtype=torch.uint8, device=dev)
         with _device_guard(dev):
             cur = torch.cuda.current_stream(dev)
             last = st["last_stream"]
@@ -714,8 +730,11 @@ def _resident_launch(dev, B, H, W, T, launch):
                 for w_ in st["work"].values():          # behind every earlier resident launch)
                     w_.zero_()
                 st["seq"] = _RES_SEQ_STEP
+                cur.synchronize()                       # (once per ~8 M calls) the completion word starts over as well
+                st["host_err_np"][1] = 0
             seq = st["seq"]
             st["seq"] = seq + _RES_SEQ_STEP
+            st["last_seq"] = seq
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
@@ -790,6 +809,87 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
     _lib.check(ok, "cspn3_forward_resident")
     if keep_history:
         return hist[int(T) - 1], hist, w8, S_out
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ K x K resident forward
+def kres_plan(K, B, H, W, T, blend=0, n_cu=0, steps_per_phase=0):
+    """The tiling cspnk_forward_resident would use (dict; `quads_per_thread` holds the OCTS per thread), or None."""
+    rp = _lib.cspn_resident_plan()
+    rp.steps_per_phase = int(steps_per_phase)
+    ok = _lib.lib().cspnk_resident_plan(int(K), int(B), int(H), int(W), int(T), int(blend), int(n_cu), ctypes.byref(rp))
+    if not ok:
+        return None
+    return {name: getattr(rp, name) for name, _ in _lib.cspn_resident_plan._fields_}
+
+
+_KRES_PLAN_CACHE = {}
+
+
+def _kres_plan_cached(K, B, H, W, T, blend, dev, steps_per_phase=0):
+    key = (K, B, H, W, T, blend, dev.index, _RESIDENT_MODE, steps_per_phase)
+    hit = _KRES_PLAN_CACHE.get(key)
+    if hit is None:
+        rp = None
+        if _RESIDENT_MODE == "on" or not _device_is_oversubscribed():
+            rp = kres_plan(K, B, H, W, T, blend, _resident_state(dev)["n_cu"], steps_per_phase)
+        cp = None
+        if rp is not None:
+            cp = _lib.cspn_resident_plan()
+            for name, _ in _lib.cspn_resident_plan._fields_:
+                if name != "debug_stamps":
+                    setattr(cp, name, rp[name])
+        if len(_KRES_PLAN_CACHE) > 1024:
+            _KRES_PLAN_CACHE.clear()
+        hit = _KRES_PLAN_CACHE[key] = (rp, cp)
+    return hit
+
+
+def pac_resident_supported(guided, x0, sparse, T, plan=None, target=None):
+    """Can this no-grad K x K forward take the weight-resident launches?  fp16 guidance (the taps stay packed in registers),
+    K = 3 or 5, whole 16-byte octs (W % 8 == 0), fp16 or fp32 depth planes, no explicit launch plan.  x0 / sparse / target
+    are the [B,H,W] planes the engine would get.  Returns the plan dict or None."""
+    B, C, H, W = guided.shape
+    K = int(math.sqrt(C + 1))
+    if _RESIDENT_MODE == "off" or plan is not None or _DEFAULT_PLANS.get(K) is not None or T < 1:
+        return None
+    if K * K != C + 1 or K not in (3, 5) or W % 8 or guided.dtype != torch.float16 or not guided.is_contiguous():
+        return None
+    if x0.dtype not in (torch.float16, torch.float32) or C * H * W >= (1 << 30):
+        return None
+    for t in (guided, x0, sparse, target):
+        if t is not None and (t.data_ptr() % 16 or (t is not guided and t.dtype != x0.dtype)):
+            return None
+    return _kres_plan_cached(K, B, H, W, int(T), int(sparse is not None), guided.device)[0]
+
+
+def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0):
+    """CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54) as weight-resident launches (cspnk_forward_resident):
+    guided [B,K*K-1,H,W] fp16, x0 / sparse [B,H,W] fp16 or fp32 -> refined [B,H,W] of that dtype; `score=(target, acc)`
+    fuses the depth metrics into the last launch."""
+    dev = _require_device(guided, x0, sparse)
+    B, C, H, W = guided.shape
+    K = int(math.sqrt(C + 1))
+    L = _lib.lib()
+    out = torch.empty((B, H, W), dtype=x0.dtype, device=dev)
+    tg, acc = score if score is not None else (None, None)
+    blend = BLEND_SPARSE if sparse is not None else BLEND_NONE
+    sdt = _dt(x0)
+    if steps_per_phase or spin_limit:
+        rp = _lib.cspn_resident_plan()
+        rp.steps_per_phase = int(steps_per_phase)
+        rp.spin_limit = int(spin_limit)
+    else:
+        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev)[1])
+
+    def launch(work, seq, host_err_ptr, stream_ptr):
+        return L.cspnk_forward_resident(_p(guided), K, _p(x0), _p(sparse), _p(out), sdt, _p(work), seq, host_err_ptr, B, H, W,
+                                        int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
+                                        None if rp is None else ctypes.byref(rp), stream_ptr)
+
+    ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt))
+    _lib.check(ok, "cspnk_forward_resident")
     return out
 
 
@@ -966,11 +1066,17 @@ class PACFunction(torch.autograd.Function):
             raise ValueError("x must be [B,C,H,W] matching guided [B,K*K-1,H,W]; got %s and %s" % (
                 tuple(x.shape), tuple(guided.shape)))
         CX = x.shape[1]
-        wk, K = pac_prepare(guided)
         sdt = x.dtype if state_dtype is None else state_dtype
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         sp = None if sp is None else sp.to(sdt)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if not need_grad and CX == 1 and guided.dtype == torch.float16:
+            g = guided if guided.is_contiguous() else guided.contiguous()
+            d0 = _plane(x, B, H, W, "x").to(sdt)
+            if pac_resident_supported(g, d0, sp, prop_time, plan) is not None:
+                # inference, weight-resident: the softmax taps never leave the registers, no tap volume
+                return pac_forward_resident(g, d0, sp, prop_time).unsqueeze(1)
+        wk, K = pac_prepare(guided)
         # the dtype-specific built-in plan serves the forward only: the reverse sweep has its own instances
         fplan = dtype_default_plan(K, wk.dtype, plan)
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
@@ -1074,13 +1180,17 @@ def pac_refine_and_score(x, guided, sparse_depth, target, acc, prop_time=24, pla
     vw = W0 if pad else 0
     B, C, H, W = guided.shape
     with torch.no_grad():
-        wk, K = pac_prepare(guided)
-        plan = dtype_default_plan(K, wk.dtype, plan)
         sdt = x.dtype if state_dtype is None else state_dtype
         d0 = _plane(x, B, H, W, "x").to(sdt)
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         sp = None if sp is None else sp.to(sdt)
         tg = _plane(target, B, H, W, "target").to(sdt)
+        if not pad and x.shape[1] == 1 and guided.dtype == torch.float16:
+            g = guided if guided.is_contiguous() else guided.contiguous()
+            if pac_resident_supported(g, d0, sp, prop_time, plan, tg) is not None:
+                return pac_forward_resident(g, d0, sp, prop_time, score=(tg, acc)).unsqueeze(1)
+        wk, K = pac_prepare(guided)
+        plan = dtype_default_plan(K, wk.dtype, plan)
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
         if scored_supported(wk, d0, sp, tg, K, prop_time, plan):
             out = propagate_scored(wk, d0, sp, K, prop_time, blend, tg, acc, plan, valid_w=vw)

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 4
+#define CSPN_ABI_VERSION 5
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -230,9 +230,14 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * has CUs (cspn3_resident_plan chunks the batch).  The device must not be shared with ANOTHER resident launch at the
  * same time (a second process on the GPU, or a second stream of this process): callers serialise resident launches per
  * device (cspn_monodepth_amd/functional.py chains them with events).  The neighbour wait is bounded (seconds): on
- * time-out the launch stores 1 to status word 1 of the workspace (and to *host_err, a host-mapped word, if given),
+ * time-out the launch stores 1 to status word 1 of the workspace (and to host_err[0], if given),
  * drains, and leaves `out` incomplete — the tiles that gave up are filled with NaN (in `out`, or in the last history
  * plane) — and the caller must check the word before trusting the result (functional.ensure_resident_ok).
+ *
+ * host_err_or_null: TWO host-mapped 32-bit words (pinned host memory the device can write): [0] receives 1 on a time-out;
+ * [1] receives `seq` when the last launch of the call has finished — the last workgroup to count itself out (status word
+ * 2 of the workspace) stores it — so a host can learn "this call is complete and host_err[0] is final" by polling host
+ * memory, without a HIP call or an event on the stream (functional._ResidentCheckpoint: the end-of-backward check).
  *
  * work: cspn3_resident_workspace_bytes(B,H,W) bytes, ZERO-initialised once by the caller, then only ever passed to this
  * entry.  seq: any value in [1, 2^31-256] that grows by at least 256 from one call on the same workspace to the next
@@ -273,6 +278,24 @@ int cspn3_forward_resident(const void* guidance, long g_batch_stride, long g_cha
 int cspn3_transposed_resident(const void* w8, const float* g_T, const float* sparse_f32_or_null, float* history, void* work,
                               unsigned seq, unsigned* host_err_or_null, int B, int H, int W, int W_valid, int T, int premask,
                               const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
+
+/* The K x K softmax / pixel-adaptive variant (reference: network/libs/post_process/CSPN_ours.py:24-54 — softmax :35, zero
+ * centre tap :37-39, prop_time x { pac.conv2d :49 -> base/pac.py:89-92, sparse blend :51-53 }) as weight-resident launches:
+ * `guided` [B, K*K-1, H, W] fp16 is read ONCE, the softmax weights stay packed in registers for all T steps, no tap volume
+ * is written (cspn_pac_prepare + cspn_propagate move 4.8x the compulsory bytes at BASELINE config 3).  K = 3 or 5; W % 8 == 0
+ * (whole 16-byte octs).  x0 / sparse / out / target are [B,H,W] planes of `state_dtype` (CSPN_F16 or CSPN_F32); with fp16
+ * planes the state is rounded to half at every phase boundary — exactly where cspn_propagate with steps_per_launch =
+ * steps_per_phase rounds it between launches, so the two schedules agree bit for bit (weights: same softmax arithmetic as
+ * cspn_pac_prepare).  Workspace, seq, host_err, plan, co-residency, time-out and completion words: exactly as
+ * cspn3_forward_resident (cspnk_resident_workspace_bytes sizes the exchange planes for the state dtype; the plan's
+ * quads_per_thread field holds the OCTS per thread).  A batch whose taps do not fit the register files of the chip is
+ * chunked into several launches of whole images (config 3: two launches of 12). */
+int cspnk_resident_plan(int K, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
+size_t cspnk_resident_workspace_bytes(int B, int H, int W, int state_dtype);
+int cspnk_forward_resident(const void* guided_f16, int K, const void* x0, const void* sparse_or_null, void* out,
+                           int state_dtype, void* work, unsigned seq, unsigned* host_err_or_null, int B, int H, int W,
+                           int T, int blend, const void* target_or_null, double* acc_or_null, int nslots,
+                           const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
 
 /* A/B + test switch (process-wide): on != 0 makes every cspn_pac_* entry skip its LDS-tiled kernels and run the generic
  * one-quad-per-thread kernels; the previous setting is stored to *previous_or_null.  The initial value is read once from

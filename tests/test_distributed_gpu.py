@@ -19,7 +19,9 @@ def _torchrun(nproc, port, script_args, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port)] + script_args
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    if out.returncode != 0:            # the whole story, not pytest's abbreviated repr of the assertion
+        print("---- stdout ----\n%s\n---- stderr ----\n%s" % (out.stdout[-4000:], out.stderr[-12000:]))
+    assert out.returncode == 0, "torchrun %s failed (rc %d): see the captured output" % (script_args[0], out.returncode)
     return out.stdout
 
 

@@ -1,0 +1,161 @@
+"""GPU tests of the weight-resident K x K launches (cspnk_forward_resident, csrc/cspnk_resident.hip): the softmax taps are
+derived once from the fp16 guidance and stay packed in registers for all T steps; the batch goes through as many launches
+of whole images as the register files of the chip need.
+
+Reference: network/libs/post_process/CSPN_ours.py:24-54 (+ network/libs/base/pac.py:89-92).  Checks: the SAME BITS as the
+multi-launch schedule (cspn_pac_prepare + cspn_propagate) when steps_per_phase = steps_per_launch — same softmax
+arithmetic, same FMA order, the state rounded to the plane dtype at the same places — the oracle within the fp16
+tolerances of tests/test_hip_production.py, the reference goldens G6, fused metrics, the loud time-out."""
+import numpy as np
+import pytest
+import torch
+
+import cspn_monodepth_amd as pkg
+from cspn_monodepth_amd import functional as F
+from conftest import golden_names, load_golden, rmse
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(x, dtype=None):
+    if x is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+class resident(object):
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = F._RESIDENT_MODE
+        F.set_resident(self.mode)
+
+    def __exit__(self, *exc):
+        F.set_resident(self.prev)
+        return False
+
+
+def inputs(c_oracle, B, H, W, K, sparse, seed=60):
+    gd = c_oracle.hash_normal(seed + K, 1, (B, K * K - 1, H, W))
+    x = c_oracle.hash_uniform(seed + K, 2, (B, 1, H, W), 0.0, 10.0)
+    s = c_oracle.hash_sparse(seed + K, 3, x, max(500.0 / (H * W), 0.02)) if sparse else None
+    return x, gd, s
+
+
+def multi_launch(x, gd, s, T, S, state):
+    """The multi-launch schedule with S steps per launch (cspn_pac_prepare + cspn_propagate), resident off."""
+    m = pkg.CSPN_ours.AffinityPropagate(T, plan=dict(steps_per_launch=S), state_dtype=state)
+    with torch.no_grad(), resident("off"):
+        return m(x, gd, sparse_depth=s)
+
+
+SHAPES = [(5, 24, 228, 304, 12, 4), (5, 24, 228, 304, 12, 6), (5, 3, 228, 304, 12, 4), (5, 1, 352, 1216, 12, 4), (5, 2, 40, 64, 12, 4),
+          (5, 2, 13, 24, 5, 5), (5, 5, 60, 72, 7, 2), (5, 1, 9, 8, 3, 2), (5, 30, 120, 160, 9, 4), (3, 24, 228, 304, 24, 8),
+          (3, 2, 37, 40, 6, 4), (3, 1, 352, 1216, 24, 6)]
+
+
+@pytest.mark.parametrize("K,B,H,W,T,S", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+@pytest.mark.parametrize("state", [None, torch.float32], ids=["state16", "state32"])
+def test_resident_equals_multi_launch_bit_for_bit(K, B, H, W, T, S, sparse, state, c_oracle):
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse)
+    xt, gt, st = dev(x, torch.float16), dev(gd, torch.float16), dev(s, torch.float16)
+    sdt = torch.float16 if state is None else state
+    assert F.kres_plan(K, B, H, W, T, int(sparse), 0, S) is not None
+    ref = multi_launch(xt, gt, st, T, S, state)
+    with torch.no_grad():
+        out = F.pac_forward_resident(gt, xt[:, 0].to(sdt).contiguous(), None if st is None else st[:, 0].to(sdt).contiguous(), T,
+                                     steps_per_phase=S)
+    torch.cuda.synchronize()
+    F.ensure_resident_ok()
+    assert out.dtype == ref.dtype == sdt
+    assert torch.equal(out, ref[:, 0]), float((out.float() - ref[:, 0].float()).abs().max())
+    if B * H * W <= 3 * 228 * 304:
+        f32 = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)      # noqa: E731
+        want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)[:, 0]
+        scale = float(np.abs(want).max())
+        o = out.float().cpu().numpy()
+        tol = (8e-3, 3e-3) if state is None else (4e-3, 1e-3)
+        assert float(np.abs(o - want).max()) <= tol[0] * scale and rmse(o, want) <= tol[1] * scale
+
+
+@pytest.mark.parametrize("state", [None, "reference"], ids=["state16", "reference"])
+def test_module_takes_the_resident_path_at_config3(state, c_oracle):
+    """BASELINE config 3 through the module (what bench.py --workload pac5 runs): the no-grad call goes to the resident
+    launches with the plan the engine picks, the result stays within the fp16 tolerances of the oracle, and agrees bit for bit
+    with the multi-launch schedule of the same phase length."""
+    K, B, H, W, T = 5, 24, 228, 304, 12
+    x, gd, s = inputs(c_oracle, B, H, W, K, True, seed=61)
+    xt, gt, st = dev(x, torch.float16), dev(gd, torch.float16), dev(s, torch.float16)
+    m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=state)
+    with torch.no_grad(), resident("on"):
+        sdt = torch.float16 if state is None else torch.float32
+        rp = F.pac_resident_supported(gt, xt[:, 0].to(sdt).contiguous(), st[:, 0].to(sdt).contiguous(), T)
+        assert rp is not None and rp["launches"] >= 2          # the taps of 24 frames do not fit the register files at once
+        out = m(xt, gt, sparse_depth=st)
+    ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], None if state is None else torch.float32)
+    F.ensure_resident_ok()
+    assert torch.equal(out, ref)
+    f32 = lambda a: a.astype(np.float16).astype(np.float32)               # noqa: E731
+    want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)
+    scale = float(np.abs(want).max())
+    o = out.float().cpu().numpy()
+    tol = (8e-3, 3e-3) if state is None else (4e-3, 1e-3)
+    assert float(np.abs(o - want).max()) <= tol[0] * scale and rmse(o, want) <= tol[1] * scale
+
+
+def test_scored_resident_forward(c_oracle):
+    """forward_scored at config 3: same refined depth as the plain call, metric sums equal the separate reduction's."""
+    K, B, H, W, T = 5, 24, 228, 304, 12
+    x, gd, s = inputs(c_oracle, B, H, W, K, False, seed=62)
+    tgt = np.maximum(x + 0.1 * c_oracle.hash_normal(63, 9, x.shape), 0.0).astype(np.float32)
+    tgt[c_oracle.hash_uniform(64, 9, x.shape) < 0.05] = 0.0
+    xt, gt, tt = dev(x, torch.float16), dev(gd, torch.float16), dev(tgt, torch.float16)
+    m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=None)
+    ev = pkg.evaluation
+    with torch.no_grad(), resident("on"):
+        acc = ev.new_accumulator(DEV)
+        out = m.forward_scored(xt, gt, None, tt, acc)
+        ref = m(xt, gt)
+        sums, _ = ev.all_gather_metric_sums(acc)
+        want = ev.metric_sums(ref, tt)
+    assert torch.equal(out, ref)
+    assert np.allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
+    assert ev.finalize_metrics(sums)["count"] == int((tgt > 0).sum())
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("g6_") if "k5" in n or "k3" in n])
+def test_reference_goldens_through_the_resident_launch(name):
+    """G6: CSPN_ours outputs captured from the reference (fp32).  Fed as fp16 guidance + fp32 state, the resident launch
+    must stay within the fp16-weight tolerance of the reference's fp32 result."""
+    z = load_golden(name)
+    x, gd = z["x"], z["guided"]
+    s = z.get("sparse")
+    T = int(z["T"])
+    if gd.shape[-1] % 8:
+        pytest.skip("W % 8 != 0: served by the multi-launch schedule")
+    gt = dev(gd, torch.float16)
+    with torch.no_grad():
+        out = F.pac_forward_resident(gt, dev(x)[:, 0].contiguous(), None if s is None else dev(s)[:, 0].contiguous(), T)
+    want = z["out"][:, 0]
+    scale = float(np.abs(want).max())
+    assert float(np.abs(out.cpu().numpy() - want).max()) <= 4e-3 * scale
+    F.ensure_resident_ok()
+
+
+def test_resident_timeout_is_loud(c_oracle):
+    K, B, H, W, T = 5, 12, 228, 304, 12
+    x, gd, _ = inputs(c_oracle, B, H, W, K, False, seed=65)
+    xt, gt = dev(x, torch.float16)[:, 0].contiguous(), dev(gd, torch.float16)
+    with torch.no_grad():
+        out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1)
+        with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
+            F.ensure_resident_ok()
+        assert bool(torch.isnan(out).any())
+        good = F.pac_forward_resident(gt, xt, None, T)
+        ref = multi_launch(xt.unsqueeze(1), gt, None, T, F.kres_plan(K, B, H, W, T)["steps_per_phase"], None)
+    assert torch.equal(good, ref[:, 0])
+    F.ensure_resident_ok()

@@ -1,22 +1,43 @@
 #!/usr/bin/env python3
-"""Developer tool: N forward+backward passes of the 3x3 module at config 2 (or --batch/--hw), nothing else — the command
-rocprofv3 wraps to profile the training-shaped kernels (history-keeping forward, WSRC=2 reverse sweep, cspn_grad_tail)."""
-import argparse, os, sys
+"""Developer tool: N forward+backward passes of the CSPN module and nothing else — the command rocprofv3 wraps to profile
+the training-shaped kernels.  Default: the 3x3 module at config 2 (history-keeping forward, reverse sweep, cspn_grad_tail);
+--K 5 [--dtype f16]: the K x K softmax module at config 3's shape (softmax prepare, history-keeping launches, transposed
+launches, the PAC backward tail)."""
+import argparse
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import cspn_monodepth_amd as pkg
+import torch                                   # noqa: E402
+import cspn_monodepth_amd as pkg               # noqa: E402
+
 ap = argparse.ArgumentParser()
-ap.add_argument("--batch", type=int, default=24); ap.add_argument("--H", type=int, default=228); ap.add_argument("--W", type=int, default=304)
-ap.add_argument("--iters", type=int, default=12); ap.add_argument("--sparse", action="store_true"); ap.add_argument("--T", type=int, default=24)
+ap.add_argument("--batch", type=int, default=24)
+ap.add_argument("--H", type=int, default=228)
+ap.add_argument("--W", type=int, default=304)
+ap.add_argument("--iters", type=int, default=12)
+ap.add_argument("--sparse", action="store_true")
+ap.add_argument("--T", type=int, default=0, help="propagation steps (default: 24 for K=3, 12 for K=5)")
+ap.add_argument("--K", type=int, default=3)
+ap.add_argument("--dtype", choices=("f32", "f16"), default="f32")
 a = ap.parse_args()
 dev = "cuda:0"
-g = torch.randn(a.batch, 12, a.H, a.W, device=dev, requires_grad=True)
-d = (torch.rand(a.batch, 1, a.H, a.W, device=dev) * 10).requires_grad_(True)
+dt = torch.float16 if a.dtype == "f16" else torch.float32
+T = a.T or (24 if a.K == 3 else 12)
+C = 12 if a.K == 3 else a.K * a.K - 1
+g = torch.randn(a.batch, C, a.H, a.W, device=dev).to(dt).requires_grad_(True)
+d = (torch.rand(a.batch, 1, a.H, a.W, device=dev) * 10).to(dt).requires_grad_(True)
 s = (d.detach() * (torch.rand_like(d) < 0.007)) if a.sparse else None
-cot = torch.randn(a.batch, 1, a.H, a.W, device=dev)
-m = pkg.CSPN_new.AffinityPropagate(a.T, 3)
+cot = torch.randn(a.batch, 1, a.H, a.W, device=dev).to(dt)
+if a.K == 3:
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    run = lambda: m(g, d, s)                   # noqa: E731
+else:
+    m = pkg.CSPN_ours.AffinityPropagate(T)
+    run = lambda: m(d, g, s)                   # noqa: E731
 for _ in range(a.iters):
-    g.grad = None; d.grad = None
-    m(g, d, s).backward(cot)
+    g.grad = None
+    d.grad = None
+    run().backward(cot)
 torch.cuda.synchronize()
 print("done", a.iters)
