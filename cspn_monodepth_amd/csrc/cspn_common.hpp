@@ -121,6 +121,25 @@ __device__ __forceinline__ float reciprocal_refined(float d) {
 // fp16) moves the numerator by ~2e-6 relative, 200x below half an fp16 ulp, and the derive of the weight-resident K x K
 // launch (cspnk_resident.hip: 24 exponentials per pixel over tile + halo) is VALU-bound on exactly these operations.
 // Every producer of fp16 softmax weights goes through this one function, so they all agree bit for bit.
+// half(a * b) with ONE rounding (v_fma_mixlo_f16 / v_fma_mixhi_f16 round the exact product to fp16, and write the low / high
+// half of `dst` leaving the other half alone): how every producer of fp16 softmax weights forms numerator * 1/sum.  Left to
+// the compiler, `__float2half_rn(e * inv)` is fused into this instruction in some kernels and stays a multiply + a conversion
+// (two roundings) in others — 6e-5 of the weights then differ by an fp16 ulp between kernels that must agree bit for bit.
+__device__ __forceinline__ unsigned mul_into_half_lo(unsigned dst, float a, float b) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(dst) : "v"(a), "v"(b));
+    return dst;
+}
+__device__ __forceinline__ unsigned mul_into_half_hi(unsigned dst, float a, float b) {
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(dst) : "v"(a), "v"(b));
+    return dst;
+}
+// numerator * (1 / sum) as the value the tap volume of type WT will hold
+template <typename WT> __device__ __forceinline__ float softmax_weight(float e, float inv) { return e * inv; }
+template <> __device__ __forceinline__ float softmax_weight<__half>(float e, float inv) {
+    const unsigned r = mul_into_half_lo(0u, e, inv);
+    return __half2float(__ushort_as_half((unsigned short)(r & 0xffffu)));
+}
+
 template <typename WT> __device__ __forceinline__ float softmax_exp(float d) { return exp_nonpositive(d); }
 template <> __device__ __forceinline__ float softmax_exp<__half>(float d) {
     return __builtin_amdgcn_exp2f(d * 1.44269502162933349609375f);

@@ -66,7 +66,7 @@ __global__ void cspn_pac_prepare_kernel(const GT* __restrict__ g, int B, int H, 
         // one reciprocal + NT multiplies instead of NT divisions (the pass is VALU-bound); den >= 1 unless NaN
         const float inv = reciprocal_refined(den);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) st1(wk + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(c, p, HW), v[c] * inv);
+        for (int c = 0; c < NT; ++c) st1(wk + (size_t)b * Taps<WT>::image_elems(NT, HW) + Taps<WT>::idx(c, p, HW), softmax_weight<WT>(v[c], inv));
     }
 }
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void cspn_pac_prepare_vec_kernel(const GT* __r
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[c][e] = v[c][e] * inv[e];
+            for (int e = 0; e < 4; ++e) v[c][e] = softmax_weight<WT>(v[c][e], inv[e]);
         store_taps_quad<NT>(wk + (size_t)b * Taps<WT>::image_elems(NT, HW), p, HW, v);
     }
 }

@@ -47,6 +47,7 @@ struct KResArgs {
     int wo, wr, hxw, hyw, dr, ls;
     int b0, nb, last_chunk;
     unsigned spin_limit;
+    unsigned long long* dbg;  // developer probe: [grid][16] wall-clock stamps (100 MHz) per workgroup, or null
 };
 
 #define GLB __attribute__((address_space(1)))
@@ -145,7 +146,48 @@ template <> struct StateIO<float> {
     static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 4u, o.a); st16_dev(b, e * 4u + 16u, o.b); }
 };
 
-__device__ __forceinline__ unsigned& comp(uint4& r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); }
+__device__ __forceinline__ unsigned pk_max_f16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// float(half `hi ? high : low` of w) + f, as ONE v_fma_mix_f32 (half * 1.0 + float): exact product, one rounding
+__device__ __forceinline__ float half_plus_float(unsigned w, int hi, float f) {
+    float out;
+    if (hi) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(f));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(f));
+    return out;
+}
+// Softmax over the NT channels of ONE pixel — the low (HF = 0) or the high half of the NT packed words — in place: raw logits
+// -> fp16 weights.  nmx = -max over the channels.  HF is a template parameter: with the asm variants selected by a loop
+// variable the compiler kept the two-trip loop rolled (selects and branches around every asm: 3x the time).
+template <int NT, int HF>
+__device__ __forceinline__ void softmax_half(unsigned (&w)[NT], float nmx) {
+    float v[NT];
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        // v - max straight from the packed half (v_fma_mix_f32: half * 1 + float, one rounding = the subtraction's)
+        v[c] = softmax_exp<__half>(half_plus_float(w[c], HF, nmx));
+        den += v[c];
+    }
+    const float inv = reciprocal_refined(den);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) w[c] = HF ? mul_into_half_hi(w[c], v[c], inv) : mul_into_half_lo(w[c], v[c], inv);
+}
+template <int NT>
+__device__ __forceinline__ void softmax_pair(unsigned (&w)[NT]) {
+    unsigned mx2 = 0xfc00fc00u;                           // (-inf, -inf): channel maximum of both pixels at once, on the raw
+#pragma unroll
+    for (int c = 0; c < NT; ++c) mx2 = pk_max_f16(mx2, w[c]);                           // halfs (exact: v_pk_max_f16)
+    const float nlo = -h2f_lo(mx2), nhi = -h2f_hi(mx2);
+    softmax_half<NT, 0>(w, nlo);
+    softmax_half<NT, 1>(w, nhi);
+}
+__device__ __forceinline__ unsigned comp(const uint4& r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); }
+__device__ __forceinline__ void set_comp(uint4& r, int k, unsigned v) {
+    if (k == 0) r.x = v; else if (k == 1) r.y = v; else if (k == 2) r.z = v; else r.w = v;
+}
 
 constexpr int KRES_THREADS = 512;
 
@@ -176,6 +218,9 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
     const unsigned HW = (unsigned)(H * W);
     const size_t plane = (size_t)a.B * HW;
     if (tid == 0) wg_bad = 0;
+    int n_stamp = 0;
+    auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
+    stamp();
     auto count_out = [&]() {                       // see cspn3_resident: completion word for host-side polling
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -291,6 +336,7 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
         }
     }
 
+    stamp();                                   // depth region parked (the first guidance loads have arrived)
     // ---- 2. softmax over the NT channels of every owned pixel, in place: raw halfs -> fp16 weights ----------------------
     // (CSPN_ours.py:35; the arithmetic of cspn_pac_prepare_vec_kernel: max, softmax_exp<__half>, sum in channel order,
     // one refined reciprocal, round to nearest even.)  One pixel at a time: 24 temporaries next to the 96 * NO tap registers.
@@ -298,27 +344,12 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
     for (int i = 0; i < NO; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            unsigned w[NT];                                   // the pixel pair q of every channel
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float v[NT];
-                float mx = -INFINITY;
+            for (int c = 0; c < NT; ++c) w[c] = comp(wpk[i][c], q);
+            softmax_pair<NT>(w);
 #pragma unroll
-                for (int c = 0; c < NT; ++c) {
-                    const unsigned w = comp(wpk[i][c], q);
-                    v[c] = hf ? h2f_hi(w) : h2f_lo(w);
-                    mx = fmaxf(mx, v[c]);
-                }
-                float den = 0.f;
-#pragma unroll
-                for (int c = 0; c < NT; ++c) { v[c] = softmax_exp<__half>(v[c] - mx); den += v[c]; }
-                const float inv = reciprocal_refined(den);
-#pragma unroll
-                for (int c = 0; c < NT; ++c) {
-                    const unsigned hb = f2h_bits(v[c] * inv);
-                    unsigned& w = comp(wpk[i][c], q);
-                    w = hf ? ((w & 0xffffu) | (hb << 16)) : ((w & 0xffff0000u) | hb);
-                }
-            }
+            for (int c = 0; c < NT; ++c) set_comp(wpk[i][c], q, w[c]);
         }
     }
 
@@ -351,6 +382,7 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
         }
     }
 
+    stamp();                                   // weights derived
     // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes ----------------------
     const bool active = r0 < wr;
     ST* __restrict__ outb = kuniform_ptr(static_cast<ST*>(a.out) + (size_t)b * HW);
@@ -510,6 +542,7 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
                 }
             }
         };
+        stamp();                               // depth staged
         const bool any = __ballot(active) != 0ull;          // wavefronts without a single owned row only keep the barriers company
         for (int s = 0; s < steps; ++s) {
             const int kind = (s == steps - 1) ? (last_phase ? 2 : 1) : 0;
@@ -517,6 +550,7 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
             if (kind == 2) fin_buf = (s + 1) & 1;
             if (kind == 0) __syncthreads();
         }
+        stamp();                               // steps of the phase done
         if (!last_phase) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's device-scope stores have landed
             __syncthreads();                                       // ... and so have everybody else's in the workgroup
@@ -543,6 +577,7 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
                 }
             }
             __syncthreads();
+            stamp();                           // neighbours' borders published
             if (wg_bad) {
                 if (tid == 0) {
                     __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -602,6 +637,7 @@ __global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs
             if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + tid, v);
         }
     }
+    stamp();                                   // epilogue done
     count_out();
 }
 
@@ -827,6 +863,7 @@ int cspnk_forward_resident(const void* guided, int K, const void* x0, const void
     a.tw = g.tw; a.th = g.th; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     a.wo = g.wo; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
     a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);
+    a.dbg = rp.debug_stamps;
     const bool clean = kregions_inside_image(g, H, W);
     const int score = acc ? 1 : 0;
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {

@@ -863,7 +863,7 @@ def pac_resident_supported(guided, x0, sparse, T, plan=None, target=None):
     return _kres_plan_cached(K, B, H, W, int(T), int(sparse is not None), guided.device)[0]
 
 
-def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0):
+def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None):
     """CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54) as weight-resident launches (cspnk_forward_resident):
     guided [B,K*K-1,H,W] fp16, x0 / sparse [B,H,W] fp16 or fp32 -> refined [B,H,W] of that dtype; `score=(target, acc)`
     fuses the depth metrics into the last launch."""
@@ -875,10 +875,11 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
     tg, acc = score if score is not None else (None, None)
     blend = BLEND_SPARSE if sparse is not None else BLEND_NONE
     sdt = _dt(x0)
-    if steps_per_phase or spin_limit:
+    if steps_per_phase or spin_limit or debug_stamps is not None:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
         rp.spin_limit = int(spin_limit)
+        rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
     else:
         rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev)[1])
 
@@ -970,8 +971,8 @@ def _check_resident_at_end_of_backward(dev):
     kernels, the first of the backward pass, have long finished, so the wait is free in a real model.  The reference
     re-raises worker errors the same way, never swallowing them (network/libs/base/encoding.py:172-174, :193-194)."""
     st = _RES.get(dev.index)
-    if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing():
-        return
+    if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing() or os.environ.get("CSPN_BWD_CHECK") == "off":
+        return                     # (CSPN_BWD_CHECK=off: A/B switch for measurements; the next resident launch still raises)
     cp = _ResidentCheckpoint(dev)
     st["dirty"] = False            # everything issued so far is covered by the checkpoint
     try:

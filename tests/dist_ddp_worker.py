@@ -79,9 +79,12 @@ def main():
         mean = torch.stack([t.to(dev) for t in parts]).mean(0)
         scale = float(mean.abs().max())
         err = float((p.grad - mean).abs().max())
-        assert scale > 0 and err <= 2e-4 * scale, "DDP gradient of %s is not the mean of the ranks' gradients: %g vs scale %g" % (k, err, scale)
-        if world > 1:
-            assert float((own[k] - mean).abs().max()) > 1e-3 * scale, "ranks saw the same data? (%s)" % k
+        # two backward passes of a 50-layer network through MIOpen's atomics-based weight gradients are not bit-reproducible:
+        # measured run to run, relative to the largest entry: 9e-4 .. 7e-3 at the heads, 1.1e-2 at the stem (the far end of
+        # the backward pass); the ranks' own gradients differ from the mean by far more (checked below)
+        assert scale > 0 and err <= 3e-2 * scale, "DDP gradient of %s is not the mean of the ranks' gradients: %g vs scale %g" % (k, err, scale)
+        if world > 1:       # the ranks' own gradients differ from the mean by far more than that noise: they saw different data
+            assert float((own[k] - mean).abs().max()) > 4 * err + 1e-6 * scale, "ranks saw the same data? (%s)" % k
     # 3. the CSPN pair inside the model against the oracle
     gd, cd, sd = (t.cpu().numpy() for t in captured["in"])
     want = c_oracle.cspn3_forward(gd, cd, sd, 24)
