@@ -763,7 +763,9 @@ bool regions_inside_image(const ResGeom& g, int H, int W, int Wv) {
 bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_user, ResGeom* best) {
     if (W % 4 != 0 || ncu < 1 || T < 1) return false;
     bool found = false;
-    for (int S = (S_user > 0 ? S_user : 8); S >= (S_user > 0 ? S_user : 4); S -= 2) {
+    // phase lengths 12 / 8 / 6 / 4: twelve (one exchange at T = 24) wins on small shards whose tiles stay at two quads per
+    // thread (NYU B = 6: 22.2 vs 23.9 us), eight everywhere else (tools/probes/resident_s_sweep.py)
+    for (int S = (S_user > 0 ? S_user : 12); S >= (S_user > 0 ? S_user : 4); S -= (S > 8 ? 4 : 2)) {
         const int Se = S > T ? T : S;
         const int hyw = Se - 1, hxw = round_up4(Se - 1);
         const int phases = ceil_div(T, Se);

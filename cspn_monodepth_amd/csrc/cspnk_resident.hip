@@ -189,15 +189,15 @@ __device__ __forceinline__ void set_comp(uint4& r, int k, unsigned v) {
     if (k == 0) r.x = v; else if (k == 1) r.y = v; else if (k == 2) r.z = v; else r.w = v;
 }
 
-constexpr int KRES_THREADS = 512;
+constexpr int KRES_THREADS = 512;        // default workgroup; 768 threads (3 wavefronts per SIMD, <= 168 VGPRs) serve one-oct strips
 
 // LDS layout of one depth buffer: dr rows of `ls` floats; a row holds the EVEN quads of its octs, E[k+1] = pixels 0..3 of oct k
 // (k = -1 .. wo: one ring oct on each side), then the ODD quads O[k+1] = pixels 4..7, each array (wo + 2) quads long.  Thread
 // (sy, sx) reads E[sx], O[sx] with ds_read_b128 (consecutive lanes = consecutive 16-byte slots: conflict-free) and the R
 // pixels left / right of its oct as the tail of O[sx-1] / the head of E[sx+1].
-template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST>
-__global__ __launch_bounds__(KRES_THREADS, 2) void cspnk_resident(const KResArgs a) {
-    constexpr int R = K / 2, NT = K * K - 1, NTH = KRES_THREADS;
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH = KRES_THREADS>
+__global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs a) {
+    constexpr int R = K / 2, NT = K * K - 1;
     static_assert(R == 1 || R == 2, "K = 3 or 5");
     using IO = StateIO<ST>;
     using Oct = typename IO::Oct;
@@ -646,7 +646,7 @@ constexpr int KRES_MAX_NO_K5 = 2;
 constexpr int KRES_MAX_NO_K3 = 4;
 
 struct KGeom {
-    int S, tiles_x, tiles_y, tw, th, no, wo, wr, hxw, hyw, dr, ls;
+    int S, tiles_x, tiles_y, tw, th, no, wo, wr, hxw, hyw, dr, ls, threads;
     int imgs_per_launch, launches;
     size_t lds_bytes;
     double cost;
@@ -701,9 +701,13 @@ bool kregions_inside_image(const KGeom& g, int H, int W) {
     return true;
 }
 
-bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, int tx, int ty, int tw, int th, KGeom* g) {
+// threads: 512 (two wavefronts per SIMD, 256 VGPRs) or 768 (three per SIMD, 168 VGPRs: one oct per thread at K = 5, two at
+// K = 3).  A step costs a SIMD (octs per thread) x (its wavefronts that own any): a 735-oct region is 4 such units on 512
+// threads (6 of 8 wavefronts busy, two octs each) and 3 on 768 (12 wavefronts, one oct each).
+bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, int tx, int ty, int tw, int th, int threads, KGeom* g) {
     const int R = K / 2;
-    const int max_no = K == 5 ? KRES_MAX_NO_K5 : KRES_MAX_NO_K3;
+    if (threads != 512 && threads != 768) return false;
+    const int max_no = threads == 768 ? (K == 5 ? 1 : 2) : (K == 5 ? KRES_MAX_NO_K5 : KRES_MAX_NO_K3);
     const int hyw = (Se - 1) * R, hxw = round_up8((Se - 1) * R);
     const int phases = ceil_div(T, Se);
     if (phases > 1 && (Se & 1)) return false;          // every phase must start in buffer 0
@@ -713,10 +717,11 @@ bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, i
     const int wo = (tw + 2 * hxw) / 8;
     if (wo > 128 || wo < 1) return false;
     const int wr = th + 2 * hyw;
-    const int no = ceil_div(wr, KRES_THREADS / wo);
+    if (wo > threads) return false;
+    const int no = ceil_div(wr, threads / wo);
     if (no > max_no) return false;
     const int dr = wr + 2 * R;
-    if (2 * dr > 2 * KRES_THREADS || dr * wo > (no + 1) * KRES_THREADS) return false;
+    if (2 * dr > 2 * threads || dr * wo > (no + 1) * threads) return false;
     const int ls = kres_row_stride(wo, no);
     const size_t ldsb = kres_lds_bytes(dr, ls, wr, wo, blend);
     if (ldsb > 160 * 1024) return false;
@@ -725,20 +730,22 @@ bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, i
     int ipl = ncu / tiles;
     if (ipl > B) ipl = B;
     const int launches = ceil_div(B, ipl);
-    *g = KGeom{Se, tx, ty, tw, th, no, wo, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, 0.0};
-    // microseconds per launch (first fit on MI355X, config 3): launch + epilogue; the derive and a step cost VALU time in
-    // proportion to the octs per thread and the wavefronts per SIMD that own any; each phase boundary a publish / wait /
-    // halo staging round trip
+    *g = KGeom{Se, tx, ty, tw, th, no, wo, wr, hxw, hyw, dr, ls, threads, ipl, launches, ldsb, 0.0};
+    // microseconds per launch, fitted on MI355X at config 3 (tools/probes/kres_probe.py plans -> profiles/r03_kres_plans.txt):
+    // launch + epilogue 3; the derive (softmax: 3.3 per unit) and every step (0.5 per unit) cost VALU time in proportion to
+    // unit = (octs per thread) x (wavefronts per SIMD that own any) — v_fma_mix_f32 issues once per 4 cycles and wavefront;
+    // each phase boundary a publish / wait / halo staging round trip of ~3.2.  Measured / modelled per launch: S=4 768 threads
+    // 39.4 / 38.3, S=6 512 threads 46.5 / 44.4, S=2 768 threads 47.1 / 47.9, S=6 768 threads (3 launches) 35.3 / 35.0.
     const int strips = ceil_div(wr, no) * wo;
     const int waves_per_simd = ceil_div(ceil_div(strips, 64), 4);
     const double per_oct = (double)no * waves_per_simd;
     const double taps = (double)(K * K - 1) / 24.0;
     const double pen = kregions_inside_image(*g, H, W) ? 1.0 : 1.1;
-    g->cost = launches * (6.0 + 2.7 * taps * per_oct + T * (0.22 * taps * per_oct * pen + 0.08) + (phases - 1) * 4.5);
+    g->cost = launches * (3.0 + 3.3 * taps * per_oct + T * (0.5 * taps * per_oct * pen + 0.08) + (phases - 1) * 3.2);
     return true;
 }
 
-bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_user, KGeom* best) {
+bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_user, int threads_user, KGeom* best) {
     if (W % 8 != 0 || ncu < 1 || T < 1 || (K != 3 && K != 5)) return false;
     bool found = false;
     const int s_hi = S_user > 0 ? S_user : (K == 3 ? 8 : 6), s_lo = S_user > 0 ? S_user : 2;
@@ -750,18 +757,21 @@ bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_
             for (int ty = 1; ty <= 64; ++ty) {
                 const int th = ceil_div(H, ty);
                 if (ty > 1 && (th < 4 || ceil_div(H, th) != ty)) continue;
-                KGeom cand;
-                if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, tx, ty, tw, th, &cand)) continue;
-                if (!found || cand.cost < best->cost) { found = true; *best = cand; }
+                for (int threads = 512; threads <= 768; threads += 256) {
+                    if (threads_user > 0 && threads != threads_user) continue;
+                    KGeom cand;
+                    if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, tx, ty, tw, th, threads, &cand)) continue;
+                    if (!found || cand.cost < best->cost) { found = true; *best = cand; }
+                }
             }
         }
     }
     return found;
 }
 
-template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST>
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH>
 int klaunch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST>;
+    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST, NTH>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -769,29 +779,36 @@ int klaunch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) 
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         granted[dev & 63].store(lds_bytes, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(KRES_THREADS), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds_bytes, st, a);
     HIP_OK(hipGetLastError());
     return 1;
 }
-template <int K, int NO, typename ST>
+template <int K, int NO, typename ST, int NTH>
 int klaunch_no(const KResArgs& a, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
 #define KRES_CASE(BL, SC, CL) \
-    if (blend == BL && score == SC && (int)clean == CL) return klaunch_inst<K, NO, BL, SC, CL, ST>(a, grid, lds, st)
+    if (blend == BL && score == SC && (int)clean == CL) return klaunch_inst<K, NO, BL, SC, CL, ST, NTH>(a, grid, lds, st)
     KRES_CASE(0, 0, 0); KRES_CASE(0, 0, 1); KRES_CASE(0, 1, 0); KRES_CASE(0, 1, 1);
     KRES_CASE(1, 0, 0); KRES_CASE(1, 0, 1); KRES_CASE(1, 1, 0); KRES_CASE(1, 1, 1);
 #undef KRES_CASE
     return fail("cspnk_forward_resident: internal dispatch");
 }
 template <int K, typename ST>
-int klaunch_k(const KResArgs& a, int no, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
+int klaunch_k(const KResArgs& a, int no, int threads, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
+    if (threads == 768) {
+        if (no == 1) return klaunch_no<K, 1, ST, 768>(a, grid, lds, blend, score, clean, st);
+        if constexpr (K == 3) {
+            if (no == 2) return klaunch_no<K, 2, ST, 768>(a, grid, lds, blend, score, clean, st);
+        }
+        return fail("cspnk_forward_resident: no 768-thread instance for K=%d with %d octs per thread", K, no);
+    }
     switch (no) {
-        case 1: return klaunch_no<K, 1, ST>(a, grid, lds, blend, score, clean, st);
-        case 2: return klaunch_no<K, 2, ST>(a, grid, lds, blend, score, clean, st);
+        case 1: return klaunch_no<K, 1, ST, 512>(a, grid, lds, blend, score, clean, st);
+        case 2: return klaunch_no<K, 2, ST, 512>(a, grid, lds, blend, score, clean, st);
         default: break;
     }
     if constexpr (K == 3) {
-        if (no == 3) return klaunch_no<K, 3, ST>(a, grid, lds, blend, score, clean, st);
-        if (no == 4) return klaunch_no<K, 4, ST>(a, grid, lds, blend, score, clean, st);
+        if (no == 3) return klaunch_no<K, 3, ST, 512>(a, grid, lds, blend, score, clean, st);
+        if (no == 4) return klaunch_no<K, 4, ST, 512>(a, grid, lds, blend, score, clean, st);
     }
     return fail("cspnk_forward_resident: no instance for K=%d with %d octs per thread", K, no);
 }
@@ -806,10 +823,10 @@ int cspnk_resident_plan(int K, int B, int H, int W, int T, int blend, int n_cu, 
     if (n_cu <= 0) n_cu = kcu_count();
     if (n_cu <= 0) return fail("cspnk_resident_plan: no device (pass n_cu > 0 to plan without one)");
     KGeom g;
-    if (T < 1 || !kres_geometry(K, B, H, W, T, blend, n_cu, out->steps_per_phase, &g))
+    if (T < 1 || !kres_geometry(K, B, H, W, T, blend, n_cu, out->steps_per_phase, out->threads, &g))
         return fail("cspnk_resident_plan: no resident tiling for K=%d B=%d %dx%d T=%d on %d CUs (W %% 8 == 0 needed)", K, B, H, W, T, n_cu);
     out->steps_per_phase = g.S; out->tiles_x = g.tiles_x; out->tiles_y = g.tiles_y; out->tile_w = g.tw; out->tile_h = g.th;
-    out->quads_per_thread = g.no; out->threads = KRES_THREADS; out->images_per_launch = g.imgs_per_launch;
+    out->quads_per_thread = g.no; out->threads = g.threads; out->images_per_launch = g.imgs_per_launch;
     out->launches = g.launches; out->lds_bytes = (int)g.lds_bytes; out->n_cu = n_cu;
     out->region_over_tile = (float)((double)(8 * g.wo) * g.wr / ((double)g.tw * g.th));
     return 1;
@@ -843,11 +860,11 @@ int cspnk_forward_resident(const void* guided, int K, const void* x0, const void
     if (plan) rp = *plan;
     if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
         const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
-        if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, &g) ||
+        if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
             (long)rp.images_per_launch * g.tiles_x * g.tiles_y > ncu)
             return fail("cspnk_forward_resident: the plan does not fit this problem / device (use cspnk_resident_plan)");
         g.imgs_per_launch = rp.images_per_launch;
-    } else if (!kres_geometry(K, B, H, W, T, blend, ncu, rp.steps_per_phase, &g)) {
+    } else if (!kres_geometry(K, B, H, W, T, blend, ncu, rp.steps_per_phase, rp.threads, &g)) {
         return fail("cspnk_forward_resident: no resident tiling for K=%d B=%d %dx%d T=%d", K, B, H, W, T);
     }
     KResArgs a{};
@@ -873,11 +890,11 @@ int cspnk_forward_resident(const void* guided, int K, const void* x0, const void
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
         if (K == 5) {
-            ok = state_dtype == CSPN_F16 ? klaunch_k<5, __half>(a, g.no, grid, g.lds_bytes, blend, score, clean, st)
-                                         : klaunch_k<5, float>(a, g.no, grid, g.lds_bytes, blend, score, clean, st);
+            ok = state_dtype == CSPN_F16 ? klaunch_k<5, __half>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st)
+                                         : klaunch_k<5, float>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
         } else {
-            ok = state_dtype == CSPN_F16 ? klaunch_k<3, __half>(a, g.no, grid, g.lds_bytes, blend, score, clean, st)
-                                         : klaunch_k<3, float>(a, g.no, grid, g.lds_bytes, blend, score, clean, st);
+            ok = state_dtype == CSPN_F16 ? klaunch_k<3, __half>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st)
+                                         : klaunch_k<3, float>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
         }
         if (!ok) return 0;
     }

@@ -813,10 +813,11 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
 
 
 # ------------------------------------------------------------------------------------------------ K x K resident forward
-def kres_plan(K, B, H, W, T, blend=0, n_cu=0, steps_per_phase=0):
+def kres_plan(K, B, H, W, T, blend=0, n_cu=0, steps_per_phase=0, threads=0):
     """The tiling cspnk_forward_resident would use (dict; `quads_per_thread` holds the OCTS per thread), or None."""
     rp = _lib.cspn_resident_plan()
     rp.steps_per_phase = int(steps_per_phase)
+    rp.threads = int(threads)
     ok = _lib.lib().cspnk_resident_plan(int(K), int(B), int(H), int(W), int(T), int(blend), int(n_cu), ctypes.byref(rp))
     if not ok:
         return None
@@ -863,7 +864,7 @@ def pac_resident_supported(guided, x0, sparse, T, plan=None, target=None):
     return _kres_plan_cached(K, B, H, W, int(T), int(sparse is not None), guided.device)[0]
 
 
-def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None):
+def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None, threads=0):
     """CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54) as weight-resident launches (cspnk_forward_resident):
     guided [B,K*K-1,H,W] fp16, x0 / sparse [B,H,W] fp16 or fp32 -> refined [B,H,W] of that dtype; `score=(target, acc)`
     fuses the depth metrics into the last launch."""
@@ -875,9 +876,10 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
     tg, acc = score if score is not None else (None, None)
     blend = BLEND_SPARSE if sparse is not None else BLEND_NONE
     sdt = _dt(x0)
-    if steps_per_phase or spin_limit or debug_stamps is not None:
+    if steps_per_phase or spin_limit or debug_stamps is not None or threads:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
+        rp.threads = int(threads)
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
     else:
@@ -927,7 +929,11 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
         p = None
         if W % 4 == 0 and w.data_ptr() % 16 == 0 and (sp32 is None or sp32.data_ptr() % 16 == 0):
             p = resolve_plan(K, B, H, W, T, True, plan)
-        if p is not None and not p["force_scalar"] and (p["quads_per_thread"], p["threads"]) in _TRANSPOSED_INSTANCES[K]:
+        gather = os.environ.get("CSPN_REVERSE_SWEEP", "auto")      # "gather" | "copy": A/B switch; auto = the measured choice
+        if gather == "auto":
+            gather = "copy" if K >= 5 else "gather"
+        if (gather == "gather" and p is not None and not p["force_scalar"]
+                and (p["quads_per_thread"], p["threads"]) in _TRANSPOSED_INSTANCES[K]):
             # transposed recurrence straight on the forward tap volume (no transposed copy)
             with _device_guard(dev):
                 ok = L.cspn_propagate_transposed(_p(w), _dt(w), _p(g_T), _p(sp32), _p(ghist), B, H, W,
@@ -935,12 +941,15 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
                                                  _plan_ptr(K, plan), _stream(dev))
             _lib.check(ok, "cspn_propagate_transposed")
         else:
+            # K >= 5: one pass that writes the transposed tap volume, then the streaming launches (packed fp16 taps, the
+            # forward's plan) — the gathering launches read 24 / 48 shifted planes with per-lane patches and measured 2.5x
+            # slower per step than streaming a prepared volume (profiles/r03_kernel_stats_train_leg_pac5.csv)
             wT = transpose_weights(w, K, H, W)
             with _device_guard(dev):
                 ok = L.cspn_propagate(_p(wT), _dt(wT), _p(g_T), _p(sp32), None, _p(ghist), None,
                                       CSPN_F32, B, H, W, int(valid_w), int(K), T,
                                       BLEND_PREMASK if sparse is not None else BLEND_NONE,
-                                      _plan_ptr(K, plan), _stream(dev))
+                                      _plan_ptr(K, dtype_default_plan(K, wT.dtype, plan)), _stream(dev))
             _lib.check(ok, "cspn_propagate(backward)")
     return g_T, ghist
 

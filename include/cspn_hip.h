@@ -246,7 +246,7 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * (status + tile flags).  Re-zeroing the control words makes any seq valid again: a captured HIP graph records that memset
  * in front of the launch and replays with a constant seq. */
 typedef struct cspn_resident_plan {
-    int steps_per_phase;   /* in: 0 = choose (8, 6 or 4); out: the value used.  Even whenever T needs more  */
+    int steps_per_phase;   /* in: 0 = choose (12, 8, 6 or 4); out: the value used.  Even whenever T needs more  */
                            /* than one phase (an odd request then has no plan); any value <= T otherwise   */
     int tiles_x, tiles_y;  /* tiles per image                                                             */
     int tile_w, tile_h;
@@ -288,7 +288,7 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
  * steps_per_phase rounds it between launches, so the two schedules agree bit for bit (weights: same softmax arithmetic as
  * cspn_pac_prepare).  Workspace, seq, host_err, plan, co-residency, time-out and completion words: exactly as
  * cspn3_forward_resident (cspnk_resident_workspace_bytes sizes the exchange planes for the state dtype; the plan's
- * quads_per_thread field holds the OCTS per thread).  A batch whose taps do not fit the register files of the chip is
+ * quads_per_thread field holds the OCTS per thread; `threads` in: 0 = choose, 512 or 768 = pin the workgroup size).  A batch whose taps do not fit the register files of the chip is
  * chunked into several launches of whole images (config 3: two launches of 12). */
 int cspnk_resident_plan(int K, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
 size_t cspnk_resident_workspace_bytes(int B, int H, int W, int state_dtype);

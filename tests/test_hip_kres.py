@@ -89,6 +89,24 @@ def test_resident_equals_multi_launch_bit_for_bit(K, B, H, W, T, S, sparse, stat
         assert float(np.abs(o - want).max()) <= tol[0] * scale and rmse(o, want) <= tol[1] * scale
 
 
+@pytest.mark.parametrize("K,B,H,W,T,S", [(5, 12, 228, 304, 12, 4), (5, 2, 40, 64, 12, 2), (3, 6, 228, 304, 24, 8), (5, 1, 352, 1216, 12, 4)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_768_thread_workgroups_give_the_same_bits(K, B, H, W, T, S, sparse, c_oracle):
+    """Three wavefronts per SIMD with one oct per thread (K = 5; two at K = 3): another mapping of pixels to threads, the same
+    arithmetic per pixel."""
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=66)
+    xt, gt, st = dev(x, torch.float16), dev(gd, torch.float16), dev(s, torch.float16)
+    if F.kres_plan(K, B, H, W, T, int(sparse), 0, S, 768) is None:
+        pytest.skip("no 768-thread tiling for this shape")
+    with torch.no_grad():
+        a = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=768)
+        b_ = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=512)
+    F.ensure_resident_ok()
+    assert torch.equal(a, b_)
+    assert torch.equal(a, multi_launch(xt, gt, st, T, S, None)[:, 0])
+
+
 @pytest.mark.parametrize("state", [None, "reference"], ids=["state16", "reference"])
 def test_module_takes_the_resident_path_at_config3(state, c_oracle):
     """BASELINE config 3 through the module (what bench.py --workload pac5 runs): the no-grad call goes to the resident

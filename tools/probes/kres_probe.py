@@ -101,6 +101,31 @@ if "stamps" in sys.argv:
             dt = t[:, k] - t[:, k - 1]
             print("  %-9s mean %.2f  min %.2f  max %.2f   (ends %.2f .. %.2f us)" % (names[k - 1], dt.mean(), dt.min(), dt.max(),
                                                                                  t[:, k].min() - t0, t[:, k].max() - t0))
+if "plans" in sys.argv:
+    xq = x[:, 0].contiguous()
+    tg = (xq.float() + 0.1).half()
+    from cspn_monodepth_amd import evaluation as ev
+    acc = ev.new_accumulator(dev)
+    for SS in (2, 4, 6):
+        for th in (512, 768):
+            rp = F.kres_plan(K, B, H, W, 12, 0, 0, SS, th)
+            if rp is None:
+                print("S=%d threads=%d: no plan" % (SS, th))
+                continue
+            res = []
+            for score in (None, (tg, acc)):
+                with torch.no_grad():
+                    for _ in range(3):
+                        F.pac_forward_resident(g, xq, None, 12, steps_per_phase=SS, threads=th, score=score)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        F.pac_forward_resident(g, xq, None, 12, steps_per_phase=SS, threads=th, score=score)
+                    e1.record()
+                    e1.synchronize()
+                res.append(e0.elapsed_time(e1) * 1e3 / 20)
+            print("S=%d threads=%d: %.1f us plain, %.1f us scored; %s" % (SS, th, res[0], res[1], {k: rp[k] for k in (
+                "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread", "images_per_launch", "launches", "region_over_tile")}))
 if "sweep" in sys.argv:
     for Bq in (12, 24):
         gq, xq = g[:Bq].contiguous(), x[:Bq, 0].contiguous()
