@@ -33,7 +33,7 @@
 //   * the step loop is unrolled by two with the LDS buffers RES_PP apart (the other buffer is an immediate offset, the
 //     carried quads alternate between two register sets instead of being copied), sits inside a wave-uniform branch,
 //     and computes unconditionally with masked stores;
-//   * v_pk_fma_f32 does not help: it issues at half the rate of v_fma_f32 here (tools/pk_fma_probe.hip).
+//   * v_pk_fma_f32 does not help: it issues at half the rate of v_fma_f32 here (tools/probes/pk_fma_probe.hip).
 #include "cspn_common.hpp"
 
 #include <atomic>

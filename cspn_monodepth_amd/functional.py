@@ -587,7 +587,7 @@ def resident_pays(B, H, W, T, blend, dev):
         return None
     # measured on MI355X (tools/bench_resident.py -> profiles/r02_resident_vs_multilaunch.jsonl): the resident schedule beats
     # the three-launch one by 35 % at config 2, ~32 % when the batch needs two resident launches (KITTI B=8, NYU B=48),
-    # 25-29 % with four and eight (NYU B=96 / 192, KITTI B=32: tools/bench_resident_big.py) and 25-40 % on per-GPU shards
+    # 25-29 % with four and eight (NYU B=96 / 192, KITTI B=32: tools/probes/bench_resident_big.py) and 25-40 % on per-GPU shards
     # (B <= 6): every launch refines whole images, so the gain does not depend on their number; only extreme halo
     # overheads are left to the multi-launch schedule
     if rp["region_over_tile"] > 3.6:

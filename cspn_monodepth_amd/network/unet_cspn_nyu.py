@@ -84,9 +84,14 @@ class _UpBlock(nn.Module):
         self.oheight, self.owidth = oheight, owidth
 
     def _up_pooling(self, x, scale=2):
-        oh = self.oheight or scale * x.shape[2]
-        ow = self.owidth or scale * x.shape[3]
-        return up_pooling(x, scale, oh, ow)
+        # Loud difference: with the constructor defaults (oheight = owidth = 0) the reference's mask loops never run
+        # (range(0, 0), unet_cspn_nyu.py:208-212) and the block returns an all-zero 2H x 2W map; no caller relies on that
+        # (every block of the model is built with its target size, :327-332), so it raises here instead of silently
+        # un-pooling to 2H x 2W.
+        if not (self.oheight and self.owidth):
+            raise ValueError("decoder block built without its target size (oheight / owidth = 0): the reference returns an "
+                             "all-zero map in that case; pass the size of the un-pooled map")
+        return up_pooling(x, scale, self.oheight, self.owidth)
 
 
 class Gudi_UpProj_Block(_UpBlock):                               # unet_cspn_nyu.py:226-260
@@ -222,7 +227,10 @@ def resnet50(pretrained=False, **kwargs):
 
 
 def resnet18(pretrained=False, **kwargs):
-    """unet_cspn_nyu.py:390-401 (as in the reference, only the ResNet-50 channel plan matches the decoder widths)."""
+    """unet_cspn_nyu.py:390-401.  Deviation: the reference hard-codes the decoder widths of the ResNet-50 plan (2048 / 1024 /
+    512 / 256, :327-330), so its resnet18 cannot run a forward (channel mismatch at the first decoder block); here the widths
+    follow the block expansion (512 e, 256 e, ...), which is the same numbers for ResNet-50 and a working model for
+    ResNet-18.  Checkpoints of the reference exist for ResNet-50 only (state_dict parity: tests, golden G13)."""
     if pretrained:
         raise RuntimeError("no pretrained checkpoint is available here; load one with model.load_state_dict(...)")
     return ResNet(BasicBlock, [2, 2, 2, 2], UpProj_Block, **kwargs)

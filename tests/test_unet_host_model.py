@@ -11,7 +11,10 @@ import numpy as np
 import pytest
 import torch
 
+import cspn_monodepth_amd as pkg
 from conftest import GOLDEN, load_golden, rmse
+
+DEV = "cuda:0"
 
 
 def test_state_dict_matches_reference_keys_and_shapes():
@@ -105,3 +108,56 @@ def test_training_step_cspn_pair_and_gradients_match_oracle(c_oracle):
     close = lambda a, b, tol: float(np.abs(a - b).max()) <= tol * max(float(np.abs(b).max()), 1e-30)   # noqa: E731
     assert close(g.grad.cpu().numpy(), wg, 5e-4) and close(c.grad.cpu().numpy(), wd, 5e-5)
     assert "libcspn_hip.so" in open("/proc/self/maps").read()
+
+
+@pytest.mark.gpu
+def test_unet_ours_tail_chain_matches_the_reference():
+    """Golden G14 (tests/golden/make_golden_r03.py, imported reference in fp64): the tail of the model get_model returns —
+    network/unet_ours.py:325-333 — as ONE chain: Gudi_UpProj_Block_Cat (un-pooling with a crop) -> the depth and guidance
+    heads -> CSPN_ours.AffinityPropagate(blur, guidance, sparse_depth=...), forward and backward.  This package's blocks
+    carry the reference's parameter names, so the reference's state_dict loads as it is."""
+    from cspn_monodepth_amd.network import unet_cspn_nyu as net
+    from cspn_monodepth_amd.network.up_pooling import up_pooling
+    z = load_golden("g14_unet_ours_tail")
+    oh1, ow1, oh2, ow2 = (int(v) for v in z["sizes"])
+    T = int(z["T"])
+    C, Co = z["feat"].shape[1], z["x"].shape[1]
+    blocks = {"cat": net.Gudi_UpProj_Block_Cat(C, Co, oh1, ow1), "head_d": net.Simple_Gudi_UpConv_Block_Last_Layer(Co, 1, oh2, ow2),
+              "head_g": net.Simple_Gudi_UpConv_Block_Last_Layer(Co, 8, oh2, ow2)}
+    for name, m in blocks.items():
+        sd = {k[len(name) + 1:]: torch.from_numpy(v) for k, v in z.items() if k.startswith(name + ".")}
+        # the golden holds the buffers AFTER the recorded training-mode pass; the pass here starts from fresh statistics
+        missing = m.load_state_dict({k: v for k, v in sd.items() if "running_" not in k}, strict=False)
+        assert all("running_" in k or "num_batches" in k for k in missing.missing_keys) and not missing.unexpected_keys
+        m.to(DEV).float().train()
+    cspn = pkg.CSPN_ours.AffinityPropagate(T)
+    feat = torch.from_numpy(z["feat"]).float().to(DEV).requires_grad_(True)
+    side = torch.from_numpy(z["side"]).float().to(DEV).requires_grad_(True)
+    sparse = torch.from_numpy(z["sparse"]).float().to(DEV)
+    with torch.no_grad():
+        up = up_pooling(feat.detach(), 2, oh1, ow1)
+    assert np.array_equal(up.cpu().numpy(), z["up"].astype(np.float32))          # zero insertion + crop: exact
+    x = blocks["cat"](feat, side)
+    blur, guid = blocks["head_d"](x), blocks["head_g"](x)
+    out = cspn(blur, guid, sparse_depth=sparse)
+    (out * torch.from_numpy(z["cot"]).float().to(DEV)).sum().backward()
+
+    def close(got, want, tol):
+        want = np.asarray(want, np.float64)
+        err = float(np.abs(got.detach().double().cpu().numpy() - want).max())
+        return err <= tol * max(1.0, float(np.abs(want).max())), err
+
+    for got, key, tol in ((x, "x", 2e-5), (blur, "blur", 2e-5), (guid, "guidance", 2e-5), (out, "out", 5e-5),
+                          (feat.grad, "grad_feat", 5e-4), (side.grad, "grad_side", 5e-4),
+                          (blocks["head_g"].conv1.weight.grad, "grad_head_g_weight", 5e-4),
+                          (blocks["cat"].conv1.weight.grad, "grad_cat_conv1_weight", 5e-4)):
+        ok, err = close(got, z[key], tol)
+        assert ok, (key, err)
+    # the running statistics after one training-mode pass equal the reference's
+    for k in ("bn1.running_mean", "bn2.running_var", "sc_bn1.running_mean"):
+        ok, err = close(blocks["cat"].state_dict()[k], z["cat." + k], 2e-5)
+        assert ok, (k, err)
+    # inference route of the same chain (no grad): the CSPN stage may take another schedule, the numbers stay
+    with torch.no_grad():
+        out2 = cspn(blur.detach(), guid.detach(), sparse_depth=sparse)
+    assert float((out2 - out.detach()).abs().max()) <= 1e-5 * float(out.abs().max())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Forward+backward timing of the 3x3 module (developer tool): training-shaped use of the engine."""
 import argparse, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cspn_monodepth_amd as pkg
 from tools.tune import timed
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: where does the resident launch spend its time?  T sweep at config 2 (derive / steps / exchanges)."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cspn_monodepth_amd import functional as F
 dev = "cuda:0"

@@ -1,6 +1,6 @@
 // coop_probe.hip — developer probe (not product): what does a neighbour-flag halo exchange between co-resident
 // workgroups cost on MI355X, and what does hipLaunchCooperativeKernel add to a launch?
-//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/coop_probe tools/coop_probe.hip && gpurun_out/coop_probe
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/coop_probe tools/probes/coop_probe.hip && gpurun_out/coop_probe
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-side cost per inference step (module.forward_scored) with a tiny batch so the GPU never back-pressures."""
 import os, sys, time, cProfile, pstats, io, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cspn_monodepth_amd as pkg
 from cspn_monodepth_amd import functional as F
 B, H, W, T = 1, 64, 64, 24

@@ -1,6 +1,6 @@
 // pk_fma_probe.hip — developer probe (not product): issue rate of v_pk_fma_f32 against v_fma_f32 on MI355X, with
 // 2 wavefronts per SIMD (the resident kernel's occupancy) and 8, as independent accumulator chains of a given number.
-//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/pk_fma_probe tools/pk_fma_probe.hip && gpurun_out/pk_fma_probe
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/pk_fma_probe tools/probes/pk_fma_probe.hip && gpurun_out/pk_fma_probe
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

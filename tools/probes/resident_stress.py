@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: hammer the resident launch and compare every output with the multi-launch result (bit-exact)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import cspn_monodepth_amd as pkg
 from cspn_monodepth_amd import functional as F
