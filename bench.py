@@ -400,7 +400,11 @@ def main():
         raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, n_dev))
     torch.cuda.set_device(local_rank % n_dev)           # (gloo dry runs may oversubscribe one GPU)
     device = torch.device("cuda", local_rank % n_dev)
-    if world > 1:
+    # CSPN_BENCH_FORCE_DIST=1 (with torchrun's environment): initialise the process group even at world size 1, so that the
+    # N > 1 code path — RCCL init with a device id, barrier, all_reduce of the elapsed time, the metrics all-gather — runs on a
+    # one-GPU box exactly as the driver's N > 1 launch line would run it
+    force_dist = os.environ.get("CSPN_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
         else:
@@ -502,9 +506,11 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    gather = lambda acc: pkg.evaluation.all_gather_metric_sums(acc, force_collective=force_dist)     # noqa: E731
 
     with torch.no_grad():
         # untimed pre-warm-up (on top of the W warm-up steps): lets the caching allocator, the lazily created
@@ -516,7 +522,7 @@ def main():
             torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
-        pkg.evaluation.all_gather_metric_sums(sums)   # untimed: first use loads the reduction kernels / sets up RCCL
+        gather(sums)                                  # untimed: first use loads the reduction kernels / sets up RCCL
         sums.zero_()
         # Rehearsal of the timed region's own sequence (fence -> instrumented steps -> gather -> fence), untimed: the first
         # step issued right after a device-wide fence costs the host 90-240 us ONCE per process (lazy runtime state; 30 us
@@ -525,7 +531,7 @@ def main():
         fence()
         step()
         step()
-        pkg.evaluation.all_gather_metric_sums(sums)
+        gather(sums)
         fence()
         sums.zero_()
         # HIP events around every 4th step only (two records cost ~3 us of stream time each step): still measured live
@@ -540,7 +546,7 @@ def main():
             if dbg_host is not None:
                 dbg_host.append(time.perf_counter())
         t_loop = time.perf_counter()
-        total, per_rank = pkg.evaluation.all_gather_metric_sums(sums)  # the only collective: 10 float64 per rank
+        total, per_rank = gather(sums)                                 # the only collective: 10 float64 per rank
         t_gather = time.perf_counter()
         fence()
         t1 = time.perf_counter()
@@ -556,7 +562,7 @@ def main():
                     " ".join("%.0f" % (e[0].elapsed_time(e[1]) * 1e3) for e in evs)), file=sys.stderr)
         F.set_event_log(None)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
@@ -854,7 +860,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -117,7 +117,7 @@ class BatchAverageMeter(object):
         return dict({k: self.sums[k] / self.count for k in METRIC_NAMES}, count=self.count)
 
 
-def all_gather_metric_sums(sums, group=None):
+def all_gather_metric_sums(sums, group=None, force_collective=False):
     """All-gather the per-rank sums (world x 10 float64) and add them.  Works with gloo (CPU) and nccl/RCCL.
 
     This is where an evaluation loop hands its numbers on, so it first waits for the weight-resident launches that
@@ -127,9 +127,10 @@ def all_gather_metric_sums(sums, group=None):
         _F.ensure_resident_ok(sums.device)
     if sums.dim() == 2:
         sums = sums.sum(0)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        total = sums.clone()                              # one rank: nothing to gather
-        return total, total.clone().unsqueeze(0)
+    initialised = dist.is_available() and dist.is_initialized()
+    if not initialised or (dist.get_world_size(group) == 1 and not force_collective):
+        total = sums.clone()                              # one rank: nothing to gather (force_collective: run the collective
+        return total, total.clone().unsqueeze(0)          # anyway — the world-size-1 RCCL test and bench.py's forced group)
     world = dist.get_world_size(group)
     src = sums.contiguous()
     if sums.is_cuda and dist.get_backend(group) == "gloo":

@@ -76,3 +76,20 @@ def test_bench_train_two_ranks_on_one_gpu():
     assert "DDP x2" in d["config"]["parallelism"] and d["value"] > 0
     assert all(v == v and abs(v) < 1e6 for v in d["loss_first_last"])
     assert d["cspn_module"]["forward_us_p50"] > 0 and d["cspn_module"]["backward_us_p50"] > 0
+
+
+def test_rccl_process_group_world_size_one():
+    """The N > 1 code path of bench.py over RCCL itself (backend nccl), as far as one GPU allows: torchrun with ONE rank and
+    CSPN_BENCH_FORCE_DIST=1 initialises the nccl process group with a device id, and the barrier, the all_reduce of the elapsed
+    time and the metrics all-gather all run as collectives (world size 1) — RCCL loads, initialises and moves the 10 sums.
+    (N > 1 over xGMI needs a multi-GPU node: only the driver has one — DESIGN.md §5.)"""
+    env = dict(os.environ, PYTHONPATH=ROOT, CSPN_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29691", "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "1", "--prewarm-s", "0.05",
+           "--no-cpu-baseline", "--no-train-leg", "--no-per-step-leg", "--cold-sets", "0", "--workload", "kitti"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        print(out.stdout[-3000:], out.stderr[-8000:])
+    assert out.returncode == 0
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["metrics_check"]["count"] > 0 and d["value"] > 0
