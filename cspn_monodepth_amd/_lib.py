@@ -20,7 +20,7 @@ HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include",
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 5          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 6          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -141,10 +141,10 @@ def _declare(lib):
                                            ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn3_transposed_resident.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, ci,
                                               ctypes.POINTER(cspn_resident_plan), vp]
-    lib.cspnk_resident_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_resident_plan)]
+    lib.cspnk_resident_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_resident_plan)]
     lib.cspnk_resident_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.cspnk_resident_workspace_bytes.restype = cs
-    lib.cspnk_forward_resident.argtypes = [vp, ci, vp, vp, vp, ci, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, vp, vp, ci,
+    lib.cspnk_forward_resident.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, vp, vp, ci,
                                            ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]

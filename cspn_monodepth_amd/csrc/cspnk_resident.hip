@@ -30,7 +30,7 @@
 namespace {
 
 struct KResArgs {
-    const __half* g;         // guided [B, K*K-1, H, W] f16
+    const void* g;           // guided [B, K*K-1, H, W] f16 or f32 (GT)
     const void* x0;          // [B,H,W] ST: the coarse depth
     const void* sparse;      // [B,H,W] ST or null
     void* out;               // [B,H,W] ST
@@ -195,9 +195,13 @@ constexpr int KRES_THREADS = 512;        // default workgroup; 768 threads (3 wa
 // (k = -1 .. wo: one ring oct on each side), then the ODD quads O[k+1] = pixels 4..7, each array (wo + 2) quads long.  Thread
 // (sy, sx) reads E[sx], O[sx] with ds_read_b128 (consecutive lanes = consecutive 16-byte slots: conflict-free) and the R
 // pixels left / right of its oct as the tail of O[sx-1] / the head of E[sx+1].
-template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH = KRES_THREADS>
+// GT = the guidance dtype: __half -> taps packed two pixels per register (v_fma_mix_f32); float -> fp32 taps, 8 (K*K-1) registers
+// per oct, plain v_fma_f32 — the configuration the reference's own model runs (unet_ours: 8-channel fp32 guidance, K = 3).
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH = KRES_THREADS, typename GT = __half>
 __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs a) {
     constexpr int R = K / 2, NT = K * K - 1;
+    constexpr bool PK = std::is_same<GT, __half>::value;
+    static_assert(PK || std::is_same<ST, float>::value, "fp32 guidance runs with fp32 depth planes");
     static_assert(R == 1 || R == 2, "K = 3 or 5");
     using IO = StateIO<ST>;
     using Oct = typename IO::Oct;
@@ -285,9 +289,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     }
 
     // ---- 1. guidance of the owned octs: NT 16-byte loads per oct, all requested before the arithmetic ------------------
-    uint4 wpk[NO][NT];
+    uint4 wpk[PK ? NO : 1][PK ? NT : 1];       // packed fp16 taps ...
+    float wf[PK ? 1 : NO][PK ? 1 : NT][8];     // ... or fp32 taps
     unsigned in_img = 0, interior = 0;
-    const __half* __restrict__ gb = kuniform_ptr(a.g + (size_t)b * NT * HW);
+    const GT* __restrict__ gb = kuniform_ptr(static_cast<const GT*>(a.g) + (size_t)b * NT * HW);
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
         const int y = yo0 + i;
@@ -296,7 +301,15 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         if (ok && y >= y0 && y < y0 + a.th && xo >= x0 && xo < x0 + a.tw) interior |= 1u << i;
         const unsigned off = ok ? (unsigned)(y * W + xo) : 0u;
 #pragma unroll
-        for (int c = 0; c < NT; ++c) wpk[i][c] = ld16(atb(gb, ((unsigned)c * HW + off) * 2u));
+        for (int c = 0; c < NT; ++c) {
+            if constexpr (PK) {
+                wpk[i][c] = ld16(atb(gb, ((unsigned)c * HW + off) * 2u));
+            } else {
+                const uint4 lo = ld16(atb(gb, ((unsigned)c * HW + off) * 4u)), hi = ld16(atb(gb, ((unsigned)c * HW + off) * 4u + 16u));
+                wf[i][c][0] = __uint_as_float(lo.x); wf[i][c][1] = __uint_as_float(lo.y); wf[i][c][2] = __uint_as_float(lo.z); wf[i][c][3] = __uint_as_float(lo.w);
+                wf[i][c][4] = __uint_as_float(hi.x); wf[i][c][5] = __uint_as_float(hi.y); wf[i][c][6] = __uint_as_float(hi.z); wf[i][c][7] = __uint_as_float(hi.w);
+            }
+        }
     }
 
     // ---- park the depth region (its loads came first: only those are waited for here) ---------------------------------
@@ -342,14 +355,30 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     // one refined reciprocal, round to nearest even.)  One pixel at a time: 24 temporaries next to the 96 * NO tap registers.
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
+        if constexpr (PK) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned w[NT];                                   // the pixel pair q of every channel
+            for (int q = 0; q < 4; ++q) {
+                unsigned w[NT];                               // the pixel pair q of every channel
 #pragma unroll
-            for (int c = 0; c < NT; ++c) w[c] = comp(wpk[i][c], q);
-            softmax_pair<NT>(w);
+                for (int c = 0; c < NT; ++c) w[c] = comp(wpk[i][c], q);
+                softmax_pair<NT>(w);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) set_comp(wpk[i][c], q, w[c]);
+                for (int c = 0; c < NT; ++c) set_comp(wpk[i][c], q, w[c]);
+            }
+        } else {
+            // fp32: the arithmetic of cspn_pac_prepare_kernel<K, float, float> (two-piece exponential, refined reciprocal)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) mx = fmaxf(mx, wf[i][c][e]);
+                float den = 0.f;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) { wf[i][c][e] = softmax_exp<float>(wf[i][c][e] - mx); den += wf[i][c][e]; }
+                const float inv = reciprocal_refined(den);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) wf[i][c][e] = softmax_weight<float>(wf[i][c][e], inv);
+            }
         }
     }
 
@@ -503,7 +532,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                         const int lin = (dy + R) * K + (dx + R);
                         const int j = lin < (K * K) / 2 ? lin : lin - 1;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[i][e] = fma_h8(wpk[i][j], e, x[R + e + dx], acc[i][e]);
+                        for (int e = 0; e < 8; ++e) {
+                            if constexpr (PK) acc[i][e] = fma_h8(wpk[PK ? i : 0][PK ? j : 0], e, x[R + e + dx], acc[i][e]);
+                            else acc[i][e] = fmaf(wf[PK ? 0 : i][PK ? 0 : j][e], x[R + e + dx], acc[i][e]);
+                        }
                     }
                 }
             }
@@ -704,10 +736,11 @@ bool kregions_inside_image(const KGeom& g, int H, int W) {
 // threads: 512 (two wavefronts per SIMD, 256 VGPRs) or 768 (three per SIMD, 168 VGPRs: one oct per thread at K = 5, two at
 // K = 3).  A step costs a SIMD (octs per thread) x (its wavefronts that own any): a 735-oct region is 4 such units on 512
 // threads (6 of 8 wavefronts busy, two octs each) and 3 on 768 (12 wavefronts, one oct each).
-bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, int tx, int ty, int tw, int th, int threads, KGeom* g) {
+bool kgeom_fill(int K, int gdt, int H, int W, int T, int blend, int ncu, int B, int Se, int tx, int ty, int tw, int th, int threads, KGeom* g) {
     const int R = K / 2;
     if (threads != 512 && threads != 768) return false;
-    const int max_no = threads == 768 ? (K == 5 ? 1 : 2) : (K == 5 ? KRES_MAX_NO_K5 : KRES_MAX_NO_K3);
+    int max_no = threads == 768 ? (K == 5 ? 1 : 2) : (K == 5 ? KRES_MAX_NO_K5 : KRES_MAX_NO_K3);
+    if (gdt == CSPN_F32) max_no = K == 3 ? (threads == 768 ? 1 : 3) : (threads == 768 ? 0 : 1);   // fp32 taps: 64 / 192 registers per oct
     const int hyw = (Se - 1) * R, hxw = round_up8((Se - 1) * R);
     const int phases = ceil_div(T, Se);
     if (phases > 1 && (Se & 1)) return false;          // every phase must start in buffer 0
@@ -739,13 +772,13 @@ bool kgeom_fill(int K, int H, int W, int T, int blend, int ncu, int B, int Se, i
     const int strips = ceil_div(wr, no) * wo;
     const int waves_per_simd = ceil_div(ceil_div(strips, 64), 4);
     const double per_oct = (double)no * waves_per_simd;
-    const double taps = (double)(K * K - 1) / 24.0;
+    const double taps = (double)(K * K - 1) / 24.0 * (gdt == CSPN_F32 ? 0.8 : 1.0);
     const double pen = kregions_inside_image(*g, H, W) ? 1.0 : 1.1;
     g->cost = launches * (3.0 + 3.3 * taps * per_oct + T * (0.5 * taps * per_oct * pen + 0.08) + (phases - 1) * 3.2);
     return true;
 }
 
-bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_user, int threads_user, KGeom* best) {
+bool kres_geometry(int K, int gdt, int B, int H, int W, int T, int blend, int ncu, int S_user, int threads_user, KGeom* best) {
     if (W % 8 != 0 || ncu < 1 || T < 1 || (K != 3 && K != 5)) return false;
     bool found = false;
     const int s_hi = S_user > 0 ? S_user : (K == 3 ? 8 : 6), s_lo = S_user > 0 ? S_user : 2;
@@ -760,7 +793,7 @@ bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_
                 for (int threads = 512; threads <= 768; threads += 256) {
                     if (threads_user > 0 && threads != threads_user) continue;
                     KGeom cand;
-                    if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, tx, ty, tw, th, threads, &cand)) continue;
+                    if (!kgeom_fill(K, gdt, H, W, T, blend, ncu, B, Se, tx, ty, tw, th, threads, &cand)) continue;
                     if (!found || cand.cost < best->cost) { found = true; *best = cand; }
                 }
             }
@@ -769,9 +802,9 @@ bool kres_geometry(int K, int B, int H, int W, int T, int blend, int ncu, int S_
     return found;
 }
 
-template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH>
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH, typename GT>
 int klaunch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST, NTH>;
+    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST, NTH, GT>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -783,10 +816,10 @@ int klaunch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) 
     HIP_OK(hipGetLastError());
     return 1;
 }
-template <int K, int NO, typename ST, int NTH>
+template <int K, int NO, typename ST, int NTH, typename GT = __half>
 int klaunch_no(const KResArgs& a, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
 #define KRES_CASE(BL, SC, CL) \
-    if (blend == BL && score == SC && (int)clean == CL) return klaunch_inst<K, NO, BL, SC, CL, ST, NTH>(a, grid, lds, st)
+    if (blend == BL && score == SC && (int)clean == CL) return klaunch_inst<K, NO, BL, SC, CL, ST, NTH, GT>(a, grid, lds, st)
     KRES_CASE(0, 0, 0); KRES_CASE(0, 0, 1); KRES_CASE(0, 1, 0); KRES_CASE(0, 1, 1);
     KRES_CASE(1, 0, 0); KRES_CASE(1, 0, 1); KRES_CASE(1, 1, 0); KRES_CASE(1, 1, 1);
 #undef KRES_CASE
@@ -813,17 +846,30 @@ int klaunch_k(const KResArgs& a, int no, int threads, int grid, size_t lds, int 
     return fail("cspnk_forward_resident: no instance for K=%d with %d octs per thread", K, no);
 }
 
+// fp32 guidance (fp32 depth planes): K = 3 with one or two octs per thread, K = 5 with one
+template <int K>
+int klaunch_f32(const KResArgs& a, int no, int threads, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
+    if (threads == 512 && no == 1) return klaunch_no<K, 1, float, 512, float>(a, grid, lds, blend, score, clean, st);
+    if constexpr (K == 3) {
+        if (threads == 512 && no == 2) return klaunch_no<K, 2, float, 512, float>(a, grid, lds, blend, score, clean, st);
+        if (threads == 512 && no == 3) return klaunch_no<K, 3, float, 512, float>(a, grid, lds, blend, score, clean, st);
+        if (threads == 768 && no == 1) return klaunch_no<K, 1, float, 768, float>(a, grid, lds, blend, score, clean, st);
+    }
+    return fail("cspnk_forward_resident: no fp32-guidance instance for K=%d with %d octs per thread on %d threads", K, no, threads);
+}
+
 }  // namespace
 
 extern "C" {
 
-int cspnk_resident_plan(int K, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* out) {
+int cspnk_resident_plan(int K, int g_dtype, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* out) {
     if (!out || B < 1 || H < 1 || W < 1 || T < 0) return fail("cspnk_resident_plan: bad arguments");
+    if (g_dtype != CSPN_F16 && g_dtype != CSPN_F32) return fail("cspnk_resident_plan: guidance dtype %d", g_dtype);
     if (K != 3 && K != 5) return fail("cspnk_resident_plan: K=%d (3 or 5)", K);
     if (n_cu <= 0) n_cu = kcu_count();
     if (n_cu <= 0) return fail("cspnk_resident_plan: no device (pass n_cu > 0 to plan without one)");
     KGeom g;
-    if (T < 1 || !kres_geometry(K, B, H, W, T, blend, n_cu, out->steps_per_phase, out->threads, &g))
+    if (T < 1 || !kres_geometry(K, g_dtype, B, H, W, T, blend, n_cu, out->steps_per_phase, out->threads, &g))
         return fail("cspnk_resident_plan: no resident tiling for K=%d B=%d %dx%d T=%d on %d CUs (W %% 8 == 0 needed)", K, B, H, W, T, n_cu);
     out->steps_per_phase = g.S; out->tiles_x = g.tiles_x; out->tiles_y = g.tiles_y; out->tile_w = g.tw; out->tile_h = g.th;
     out->quads_per_thread = g.no; out->threads = g.threads; out->images_per_launch = g.imgs_per_launch;
@@ -838,16 +884,18 @@ size_t cspnk_resident_workspace_bytes(int B, int H, int W, int state_dtype) {
     return ((planes + 15) & ~(size_t)15) + ((flags + 15) & ~(size_t)15);
 }
 
-int cspnk_forward_resident(const void* guided, int K, const void* x0, const void* sparse, void* out, int state_dtype,
+int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x0, const void* sparse, void* out, int state_dtype,
                            void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend,
                            const void* target, double* acc, int nslots, const cspn_resident_plan* plan, cspn_stream_t stream) {
     if (!guided || !x0 || !out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1) return fail("cspnk_forward_resident: bad arguments");
     if (K != 3 && K != 5) return fail("cspnk_forward_resident: K=%d (3 or 5)", K);
     if (state_dtype != CSPN_F16 && state_dtype != CSPN_F32) return fail("cspnk_forward_resident: state dtype %d", state_dtype);
+    if (g_dtype != CSPN_F16 && g_dtype != CSPN_F32) return fail("cspnk_forward_resident: guidance dtype %d", g_dtype);
+    if (g_dtype == CSPN_F32 && state_dtype != CSPN_F32) return fail("cspnk_forward_resident: fp32 guidance runs with fp32 depth planes");
     if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspnk_forward_resident: blend %d", blend);
     if (blend && !sparse) return fail("cspnk_forward_resident: blend needs sparse");
     if ((target || acc) && (!target || !acc || nslots < 1)) return fail("cspnk_forward_resident: scoring needs target, acc and nslots >= 1");
-    if (W & 7) return fail("cspnk_forward_resident: W must be a multiple of 8 (whole 16-byte octs of fp16 guidance)");
+    if (W & 7) return fail("cspnk_forward_resident: W must be a multiple of 8 (whole octs of guidance)");
     if ((long)(K * K - 1) * H * W >= (1L << 30)) return fail("cspnk_forward_resident: guidance images of >= 2^30 elements are not supported (32-bit offsets)");
     if (!aligned16(guided) || !aligned16(x0) || !aligned16(out) || !aligned16(work) || (sparse && !aligned16(sparse)) || (target && !aligned16(target)))
         return fail("cspnk_forward_resident: tensors must be 16-byte aligned");
@@ -860,15 +908,15 @@ int cspnk_forward_resident(const void* guided, int K, const void* x0, const void
     if (plan) rp = *plan;
     if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
         const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
-        if (!kgeom_fill(K, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
+        if (!kgeom_fill(K, g_dtype, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
             (long)rp.images_per_launch * g.tiles_x * g.tiles_y > ncu)
             return fail("cspnk_forward_resident: the plan does not fit this problem / device (use cspnk_resident_plan)");
         g.imgs_per_launch = rp.images_per_launch;
-    } else if (!kres_geometry(K, B, H, W, T, blend, ncu, rp.steps_per_phase, rp.threads, &g)) {
+    } else if (!kres_geometry(K, g_dtype, B, H, W, T, blend, ncu, rp.steps_per_phase, rp.threads, &g)) {
         return fail("cspnk_forward_resident: no resident tiling for K=%d B=%d %dx%d T=%d", K, B, H, W, T);
     }
     KResArgs a{};
-    a.g = static_cast<const __half*>(guided); a.x0 = x0; a.sparse = sparse; a.out = out;
+    a.g = guided; a.x0 = x0; a.sparse = sparse; a.out = out;
     const size_t planes = (((size_t)2 * B * H * W * esize(state_dtype)) + 15) & ~(size_t)15;
     a.xbuf = work;
     a.status = reinterpret_cast<unsigned*>(static_cast<char*>(work) + planes);
@@ -889,7 +937,10 @@ int cspnk_forward_resident(const void* guided, int K, const void* x0, const void
         a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
-        if (K == 5) {
+        if (g_dtype == CSPN_F32) {
+            ok = K == 5 ? klaunch_f32<5>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st)
+                        : klaunch_f32<3>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
+        } else if (K == 5) {
             ok = state_dtype == CSPN_F16 ? klaunch_k<5, __half>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st)
                                          : klaunch_k<5, float>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
         } else {

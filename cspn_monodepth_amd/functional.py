@@ -813,12 +813,13 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
 
 
 # ------------------------------------------------------------------------------------------------ K x K resident forward
-def kres_plan(K, B, H, W, T, blend=0, n_cu=0, steps_per_phase=0, threads=0):
-    """The tiling cspnk_forward_resident would use (dict; `quads_per_thread` holds the OCTS per thread), or None."""
+def kres_plan(K, B, H, W, T, blend=0, n_cu=0, steps_per_phase=0, threads=0, g_dtype=CSPN_F16):
+    """The tiling cspnk_forward_resident would use (dict; `quads_per_thread` holds the OCTS per thread), or None.
+    g_dtype: CSPN_F16 (packed taps) or CSPN_F32 (fp32 taps: fewer octs fit a thread)."""
     rp = _lib.cspn_resident_plan()
     rp.steps_per_phase = int(steps_per_phase)
     rp.threads = int(threads)
-    ok = _lib.lib().cspnk_resident_plan(int(K), int(B), int(H), int(W), int(T), int(blend), int(n_cu), ctypes.byref(rp))
+    ok = _lib.lib().cspnk_resident_plan(int(K), int(g_dtype), int(B), int(H), int(W), int(T), int(blend), int(n_cu), ctypes.byref(rp))
     if not ok:
         return None
     return {name: getattr(rp, name) for name, _ in _lib.cspn_resident_plan._fields_}
@@ -827,13 +828,13 @@ def kres_plan(K, B, H, W, T, blend=0, n_cu=0, steps_per_phase=0, threads=0):
 _KRES_PLAN_CACHE = {}
 
 
-def _kres_plan_cached(K, B, H, W, T, blend, dev, steps_per_phase=0):
-    key = (K, B, H, W, T, blend, dev.index, _RESIDENT_MODE, steps_per_phase)
+def _kres_plan_cached(K, B, H, W, T, blend, dev, steps_per_phase=0, g_dtype=CSPN_F16):
+    key = (K, B, H, W, T, blend, dev.index, _RESIDENT_MODE, steps_per_phase, g_dtype)
     hit = _KRES_PLAN_CACHE.get(key)
     if hit is None:
         rp = None
         if _RESIDENT_MODE == "on" or not _device_is_oversubscribed():
-            rp = kres_plan(K, B, H, W, T, blend, _resident_state(dev)["n_cu"], steps_per_phase)
+            rp = kres_plan(K, B, H, W, T, blend, _resident_state(dev)["n_cu"], steps_per_phase, 0, g_dtype)
         cp = None
         if rp is not None:
             cp = _lib.cspn_resident_plan()
@@ -847,21 +848,23 @@ def _kres_plan_cached(K, B, H, W, T, blend, dev, steps_per_phase=0):
 
 
 def pac_resident_supported(guided, x0, sparse, T, plan=None, target=None):
-    """Can this no-grad K x K forward take the weight-resident launches?  fp16 guidance (the taps stay packed in registers),
-    K = 3 or 5, whole 16-byte octs (W % 8 == 0), fp16 or fp32 depth planes, no explicit launch plan.  x0 / sparse / target
+    """Can this no-grad K x K forward take the weight-resident launches?  fp16 guidance (the taps stay packed in registers) or
+    fp32 guidance with fp32 planes (fp32 taps), K = 3 or 5, whole 16-byte octs (W % 8 == 0), fp16 or fp32 depth planes, no explicit launch plan.  x0 / sparse / target
     are the [B,H,W] planes the engine would get.  Returns the plan dict or None."""
     B, C, H, W = guided.shape
     K = int(math.sqrt(C + 1))
     if _RESIDENT_MODE == "off" or plan is not None or _DEFAULT_PLANS.get(K) is not None or T < 1:
         return None
-    if K * K != C + 1 or K not in (3, 5) or W % 8 or guided.dtype != torch.float16 or not guided.is_contiguous():
+    if K * K != C + 1 or K not in (3, 5) or W % 8 or guided.dtype not in (torch.float16, torch.float32) or not guided.is_contiguous():
         return None
     if x0.dtype not in (torch.float16, torch.float32) or C * H * W >= (1 << 30):
+        return None
+    if guided.dtype == torch.float32 and x0.dtype != torch.float32:
         return None
     for t in (guided, x0, sparse, target):
         if t is not None and (t.data_ptr() % 16 or (t is not guided and t.dtype != x0.dtype)):
             return None
-    return _kres_plan_cached(K, B, H, W, int(T), int(sparse is not None), guided.device)[0]
+    return _kres_plan_cached(K, B, H, W, int(T), int(sparse is not None), guided.device, 0, _dt(guided))[0]
 
 
 def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None, threads=0):
@@ -883,10 +886,10 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
     else:
-        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev)[1])
+        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, _dt(guided))[1])
 
     def launch(work, seq, host_err_ptr, stream_ptr):
-        return L.cspnk_forward_resident(_p(guided), K, _p(x0), _p(sparse), _p(out), sdt, _p(work), seq, host_err_ptr, B, H, W,
+        return L.cspnk_forward_resident(_p(guided), _dt(guided), K, _p(x0), _p(sparse), _p(out), sdt, _p(work), seq, host_err_ptr, B, H, W,
                                         int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                         None if rp is None else ctypes.byref(rp), stream_ptr)
 
@@ -1080,7 +1083,7 @@ class PACFunction(torch.autograd.Function):
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         sp = None if sp is None else sp.to(sdt)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        if not need_grad and CX == 1 and guided.dtype == torch.float16:
+        if not need_grad and CX == 1:
             g = guided if guided.is_contiguous() else guided.contiguous()
             d0 = _plane(x, B, H, W, "x").to(sdt)
             if pac_resident_supported(g, d0, sp, prop_time, plan) is not None:
@@ -1195,7 +1198,7 @@ def pac_refine_and_score(x, guided, sparse_depth, target, acc, prop_time=24, pla
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         sp = None if sp is None else sp.to(sdt)
         tg = _plane(target, B, H, W, "target").to(sdt)
-        if not pad and x.shape[1] == 1 and guided.dtype == torch.float16:
+        if not pad and x.shape[1] == 1:
             g = guided if guided.is_contiguous() else guided.contiguous()
             if pac_resident_supported(g, d0, sp, prop_time, plan, tg) is not None:
                 return pac_forward_resident(g, d0, sp, prop_time, score=(tg, acc)).unsqueeze(1)

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 5
+#define CSPN_ABI_VERSION 6
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -281,18 +281,19 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
 
 /* The K x K softmax / pixel-adaptive variant (reference: network/libs/post_process/CSPN_ours.py:24-54 — softmax :35, zero
  * centre tap :37-39, prop_time x { pac.conv2d :49 -> base/pac.py:89-92, sparse blend :51-53 }) as weight-resident launches:
- * `guided` [B, K*K-1, H, W] fp16 is read ONCE, the softmax weights stay packed in registers for all T steps, no tap volume
- * is written (cspn_pac_prepare + cspn_propagate move 4.8x the compulsory bytes at BASELINE config 3).  K = 3 or 5; W % 8 == 0
- * (whole 16-byte octs).  x0 / sparse / out / target are [B,H,W] planes of `state_dtype` (CSPN_F16 or CSPN_F32); with fp16
+ * `guided` [B, K*K-1, H, W] (g_dtype fp16 or fp32) is read ONCE, the softmax weights stay in registers for all T steps —
+ * fp16 guidance: taps packed two pixels per register; fp32 guidance (fp32 depth planes only; what the reference's unet_ours
+ * feeds: 8-channel fp32, K = 3): fp32 taps, the 1e-5 parity of the multi-launch fp32 path — no tap volume is written
+ * (cspn_pac_prepare + cspn_propagate move 4.8x the compulsory bytes at BASELINE config 3).  K = 3 or 5; W % 8 == 0 (whole octs).  x0 / sparse / out / target are [B,H,W] planes of `state_dtype` (CSPN_F16 or CSPN_F32); with fp16
  * planes the state is rounded to half at every phase boundary — exactly where cspn_propagate with steps_per_launch =
  * steps_per_phase rounds it between launches, so the two schedules agree bit for bit (weights: same softmax arithmetic as
  * cspn_pac_prepare).  Workspace, seq, host_err, plan, co-residency, time-out and completion words: exactly as
  * cspn3_forward_resident (cspnk_resident_workspace_bytes sizes the exchange planes for the state dtype; the plan's
  * quads_per_thread field holds the OCTS per thread; `threads` in: 0 = choose, 512 or 768 = pin the workgroup size).  A batch whose taps do not fit the register files of the chip is
  * chunked into several launches of whole images (config 3: two launches of 12). */
-int cspnk_resident_plan(int K, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
+int cspnk_resident_plan(int K, int g_dtype, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
 size_t cspnk_resident_workspace_bytes(int B, int H, int W, int state_dtype);
-int cspnk_forward_resident(const void* guided_f16, int K, const void* x0, const void* sparse_or_null, void* out,
+int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x0, const void* sparse_or_null, void* out,
                            int state_dtype, void* work, unsigned seq, unsigned* host_err_or_null, int B, int H, int W,
                            int T, int blend, const void* target_or_null, double* acc_or_null, int nslots,
                            const cspn_resident_plan* plan_or_null, cspn_stream_t stream);

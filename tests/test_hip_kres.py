@@ -107,6 +107,47 @@ def test_768_thread_workgroups_give_the_same_bits(K, B, H, W, T, S, sparse, c_or
     assert torch.equal(a, multi_launch(xt, gt, st, T, S, None)[:, 0])
 
 
+F32_SHAPES = [(3, 24, 228, 304, 24, 8), (3, 3, 228, 304, 24, 6), (3, 2, 37, 40, 6, 4), (3, 1, 352, 1216, 24, 8), (5, 2, 40, 64, 12, 4),
+              (5, 6, 228, 304, 12, 4), (3, 5, 60, 72, 7, 2)]
+
+
+@pytest.mark.parametrize("K,B,H,W,T,S", F32_SHAPES, ids=["x".join(map(str, s)) for s in F32_SHAPES])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_fp32_guidance_resident_equals_multi_launch(K, B, H, W, T, S, sparse, c_oracle):
+    """fp32 guidance + fp32 planes — what the reference's own model feeds the module (unet_ours.py:279, :333: 8-channel fp32
+    guidance, K = 3, 24 steps): fp32 taps in registers, softmax arithmetic of cspn_pac_prepare_kernel<float>, plain FMAs in
+    the multi-launch order: the same bits as cspn_pac_prepare + cspn_propagate, and the north-star 1e-5 against the oracle."""
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=67)
+    xt, gt, st = dev(x), dev(gd), dev(s)
+    if F.kres_plan(K, B, H, W, T, int(sparse), 0, S, 0, F.CSPN_F32) is None:
+        pytest.skip("no fp32-tap tiling for this shape / phase length")
+    ref = multi_launch(xt, gt, st, T, S, None)
+    with torch.no_grad():
+        out = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S)
+    F.ensure_resident_ok()
+    assert out.dtype == torch.float32 and torch.equal(out, ref[:, 0]), float((out - ref[:, 0]).abs().max())
+    if B * H * W <= 3 * 228 * 304:
+        want = c_oracle.pac_forward(x, gd, s, T)[:, 0]
+        o = out.cpu().numpy()
+        assert float(np.abs(o - want).max()) <= 1e-5 * float(np.abs(want).max()) and rmse(o, want) <= 1e-4
+
+
+def test_unet_ours_configuration_takes_the_resident_path(c_oracle):
+    """CSPN_ours.AffinityPropagate(24) on an 8-channel fp32 guidance at B = 24, 228 x 304 with a sparse depth — the call of
+    unet_ours.py:333 at the reference's batch size — under no_grad: resident launches, same bits as the multi-launch schedule."""
+    K, B, H, W, T = 3, 24, 228, 304, 24
+    x, gd, s = inputs(c_oracle, B, H, W, K, True, seed=68)
+    xt, gt, st = dev(x), dev(gd), dev(s)
+    m = pkg.CSPN_ours.AffinityPropagate(T)
+    with torch.no_grad(), resident("on"):
+        rp = F.pac_resident_supported(gt, xt[:, 0].contiguous(), st[:, 0].contiguous(), T)
+        assert rp is not None
+        out = m(xt, gt, sparse_depth=st)
+    ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], None)
+    F.ensure_resident_ok()
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("state", [None, "reference"], ids=["state16", "reference"])
 def test_module_takes_the_resident_path_at_config3(state, c_oracle):
     """BASELINE config 3 through the module (what bench.py --workload pac5 runs): the no-grad call goes to the resident

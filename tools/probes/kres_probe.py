@@ -126,6 +126,36 @@ if "plans" in sys.argv:
                 res.append(e0.elapsed_time(e1) * 1e3 / 20)
             print("S=%d threads=%d: %.1f us plain, %.1f us scored; %s" % (SS, th, res[0], res[1], {k: rp[k] for k in (
                 "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread", "images_per_launch", "launches", "region_over_tile")}))
+if "f32" in sys.argv:
+    # the reference model's own configuration: K = 3, 8-channel fp32 guidance, T = 24 (unet_ours.py:279, :305, :333)
+    for Kq, Tq in ((3, 24), (5, 12)):
+        gq = torch.randn(B, Kq * Kq - 1, H, W, device=dev)
+        xq = torch.rand(B, 1, H, W, device=dev) * 10
+        mq = pkg.CSPN_ours.AffinityPropagate(Tq)
+
+        def timeit(fn):
+            with torch.no_grad():
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                e1.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / 20
+        F.set_resident("off")
+        t_multi = timeit(lambda: mq(xq, gq))
+        F.set_resident("auto")
+        print("fp32 K=%d T=%d B=%d: multi-launch %.1f us" % (Kq, Tq, B, t_multi))
+        for SS in (0, 4, 6, 8):
+            for th in (0, 512, 768):
+                rp = F.kres_plan(Kq, B, H, W, Tq, 0, 0, SS, th, F.CSPN_F32)
+                if rp is None:
+                    continue
+                t = timeit(lambda: F.pac_forward_resident(gq, xq[:, 0].contiguous(), None, Tq, steps_per_phase=SS, threads=th))
+                print("   resident S=%d threads=%d: %.1f us  %s" % (SS, th, t, {k: rp[k] for k in (
+                    "steps_per_phase", "tiles_x", "tiles_y", "quads_per_thread", "threads", "images_per_launch", "launches")}))
 if "sweep" in sys.argv:
     for Bq in (12, 24):
         gq, xq = g[:Bq].contiguous(), x[:Bq, 0].contiguous()
