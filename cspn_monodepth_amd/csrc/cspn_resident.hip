@@ -176,8 +176,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // The shift never moves a region start before the previous tile's start, so that the halo always comes from the 8
     // ADJACENT tiles (the ones the exchange waits for) — a last tile cut short by the image edge keeps some out-of-image
     // rows / columns instead, and its wavefronts run the step body with the zero-padding selects.
-    const int rx0 = max(max(0, x0 - a.tw), min(x0 - a.hxw, W - 4 * wq));
-    const int ry0 = max(max(0, y0 - a.th), min(y0 - a.hyw, H - wr));
+    // (the "previous tile's start" bound belongs to the exchange: a single-phase launch stages everything from the coarse
+    // depth, and its halo may be deeper than a tile — there the bound would cut the region short of y0 - hyw)
+    const bool exch = a.T > a.S;
+    const int rx0 = max(exch ? max(0, x0 - a.tw) : 0, min(x0 - a.hxw, W - 4 * wq));
+    const int ry0 = max(exch ? max(0, y0 - a.th) : 0, min(y0 - a.hyw, H - wr));
     const int xq = rx0 + 4 * sx;
     const int yq0 = ry0 + r0;
     const bool x_in = (xq >= 0) && (xq < a.Wv);
@@ -739,19 +742,20 @@ size_t res_lds_bytes(int dr, int ls, int wr, int wq, int blend) {
 }
 
 // Mirror of the kernel's region placement: does every region of every tile lie inside the (valid part of the) image?
-bool regions_inside_image(const ResGeom& g, int H, int W, int Wv) {
+bool regions_inside_image(const ResGeom& g, int H, int W, int Wv, int T) {
     if (Wv != W) return false;
+    const bool exch = T > g.S;            // mirrors the kernel: see the region origin there
     for (int tx = 0; tx < g.tiles_x; ++tx) {
         const int x0 = tx * g.tw;
         int rx0 = x0 - g.hxw; if (rx0 > W - 4 * g.wq) rx0 = W - 4 * g.wq;
-        int lo = x0 - g.tw; if (lo < 0) lo = 0;
+        int lo = exch ? x0 - g.tw : 0; if (lo < 0) lo = 0;
         if (rx0 < lo) rx0 = lo;
         if (rx0 + 4 * g.wq > W) return false;
     }
     for (int ty = 0; ty < g.tiles_y; ++ty) {
         const int y0 = ty * g.th;
         int ry0 = y0 - g.hyw; if (ry0 > H - g.wr) ry0 = H - g.wr;
-        int lo = y0 - g.th; if (lo < 0) lo = 0;
+        int lo = exch ? y0 - g.th : 0; if (lo < 0) lo = 0;
         if (ry0 < lo) ry0 = lo;
         if (ry0 + g.wr > H) return false;
     }
@@ -798,7 +802,7 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
                 // derive (~2 us per quad of a thread), T steps (VALU-bound: 0.13 us per quad; x 1.13 with the zero-padding
                 // selects of a launch whose regions stick out of the image), and per phase boundary the publish / wait /
                 // halo staging (3 us + the border bytes)
-                const double pen = regions_inside_image(cand, H, W, W) ? 1.0 : 1.13;
+                const double pen = regions_inside_image(cand, H, W, W, T) ? 1.0 : 1.13;
                 const double cost = launches * (8.0 + 2.0 * nq + T * (0.13 * nq + 0.1) * pen + (phases - 1) * (3.0 + 0.6 * nq));
                 if (!found || cost < best->cost) {
                     found = true;
@@ -968,7 +972,7 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     a.wq = g.wq; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
     a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);   // x (sc1 load + s_sleep) ~ seconds
     a.dbg = rp.debug_stamps;
-    const bool clean = regions_inside_image(g, H, W, a.Wv);
+    const bool clean = regions_inside_image(g, H, W, a.Wv, T);
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;

@@ -245,8 +245,11 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     const int r0 = sy * NO;
     // region origin, shifted back into the image at image edges (cspn3_resident: never before the previous tile's start, so
     // that the halo always comes from the 8 adjacent tiles)
-    const int rx0 = max(max(0, x0 - a.tw), min(x0 - a.hxw, W - 8 * wo));
-    const int ry0 = max(max(0, y0 - a.th), min(y0 - a.hyw, H - wr));
+    // (the "previous tile's start" bound belongs to the exchange: a single-phase launch stages everything from the coarse
+    // depth, and its halo may be deeper than a tile — there the bound would cut the region short of y0 - hyw)
+    const bool exch = a.T > a.S;
+    const int rx0 = max(exch ? max(0, x0 - a.tw) : 0, min(x0 - a.hxw, W - 8 * wo));
+    const int ry0 = max(exch ? max(0, y0 - a.th) : 0, min(y0 - a.hyw, H - wr));
     const int xo = rx0 + 8 * sx;
     const int yo0 = ry0 + r0;
     const bool x_in = xo < W;                  // W % 8 == 0: an oct lies inside the image or outside as a whole
@@ -715,18 +718,19 @@ size_t kres_lds_bytes(int dr, int ls, int wr, int wo, int blend) {
     return ((size_t)2 * dr * ls + (size_t)(blend ? 2 : 0) * wr * wo * 8 + 16 * 10) * sizeof(float);
 }
 
-bool kregions_inside_image(const KGeom& g, int H, int W) {
+bool kregions_inside_image(const KGeom& g, int H, int W, int T) {
+    const bool exch = T > g.S;            // mirrors the kernel: see the region origin there
     for (int tx = 0; tx < g.tiles_x; ++tx) {
         const int x0 = tx * g.tw;
         int rx0 = x0 - g.hxw; if (rx0 > W - 8 * g.wo) rx0 = W - 8 * g.wo;
-        int lo = x0 - g.tw; if (lo < 0) lo = 0;
+        int lo = exch ? x0 - g.tw : 0; if (lo < 0) lo = 0;
         if (rx0 < lo) rx0 = lo;
         if (rx0 + 8 * g.wo > W) return false;
     }
     for (int ty = 0; ty < g.tiles_y; ++ty) {
         const int y0 = ty * g.th;
         int ry0 = y0 - g.hyw; if (ry0 > H - g.wr) ry0 = H - g.wr;
-        int lo = y0 - g.th; if (lo < 0) lo = 0;
+        int lo = exch ? y0 - g.th : 0; if (lo < 0) lo = 0;
         if (ry0 < lo) ry0 = lo;
         if (ry0 + g.wr > H) return false;
     }
@@ -773,7 +777,7 @@ bool kgeom_fill(int K, int gdt, int H, int W, int T, int blend, int ncu, int B, 
     const int waves_per_simd = ceil_div(ceil_div(strips, 64), 4);
     const double per_oct = (double)no * waves_per_simd;
     const double taps = (double)(K * K - 1) / 24.0 * (gdt == CSPN_F32 ? 0.8 : 1.0);
-    const double pen = kregions_inside_image(*g, H, W) ? 1.0 : 1.1;
+    const double pen = kregions_inside_image(*g, H, W, T) ? 1.0 : 1.1;
     g->cost = launches * (3.0 + 3.3 * taps * per_oct + T * (0.5 * taps * per_oct * pen + 0.08) + (phases - 1) * 3.2);
     return true;
 }
@@ -929,7 +933,7 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
     a.wo = g.wo; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
     a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);
     a.dbg = rp.debug_stamps;
-    const bool clean = kregions_inside_image(g, H, W);
+    const bool clean = kregions_inside_image(g, H, W, T);
     const int score = acc ? 1 : 0;
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;

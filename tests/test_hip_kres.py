@@ -225,3 +225,71 @@ def test_resident_timeout_is_loud(c_oracle):
         ref = multi_launch(xt.unsqueeze(1), gt, None, T, F.kres_plan(K, B, H, W, T)["steps_per_phase"], None)
     assert torch.equal(good, ref[:, 0])
     F.ensure_resident_ok()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_against_the_oracle_and_the_multi_launch_schedule(seed, c_oracle):
+    """Seeded sweep over K, dtypes, batch, image sizes (tiny images, single rows of tiles, regions that cannot be shifted into
+    the image), step counts incl. odd ones and single-phase runs, phase lengths and workgroup sizes: the resident launch must
+    equal the multi-launch schedule of the same phase length bit for bit and stay within the dtype's tolerance of the oracle."""
+    rng = np.random.default_rng(4200 + seed)
+    done = 0
+    for _ in range(40):
+        K = int(rng.choice([3, 5]))
+        f32 = bool(rng.random() < 0.4)
+        B = int(rng.integers(1, 7))
+        H = int(rng.integers(1, 90))
+        W = int(8 * rng.integers(1, 20))
+        T = int(rng.integers(1, 14))
+        S = int(rng.choice([0, 2, 4, 6, 8]))
+        threads = int(rng.choice([0, 512, 768]))
+        sparse = bool(rng.random() < 0.5)
+        gdt = F.CSPN_F32 if f32 else F.CSPN_F16
+        rp = F.kres_plan(K, B, H, W, T, int(sparse), 0, S, threads, gdt)
+        if rp is None:
+            continue
+        x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=70 + seed)
+        tdt = torch.float32 if f32 else torch.float16
+        xt, gt, st = dev(x, tdt), dev(gd, tdt), dev(s, tdt)
+        state = None if (f32 or rng.random() < 0.5) else torch.float32
+        sdt = tdt if state is None else state
+        ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], state)
+        with torch.no_grad():
+            out = F.pac_forward_resident(gt, xt[:, 0].to(sdt).contiguous(), None if st is None else st[:, 0].to(sdt).contiguous(), T,
+                                         steps_per_phase=S, threads=threads)
+        case = (K, f32, B, H, W, T, S, threads, sparse, str(state), rp["tiles_x"], rp["tiles_y"], rp["quads_per_thread"])
+        assert torch.equal(out, ref[:, 0]), case
+        rnd = (lambda a: None if a is None else a.astype(np.float32)) if f32 else (
+            lambda a: None if a is None else a.astype(np.float16).astype(np.float32))
+        want = c_oracle.pac_forward(rnd(x), rnd(gd), rnd(s), T)[:, 0]
+        scale = max(float(np.abs(want).max()), 1e-6)
+        tol = 1e-5 if f32 else (8e-3 if sdt == torch.float16 else 4e-3)
+        assert float(np.abs(out.float().cpu().numpy() - want).max()) <= tol * scale, case
+        done += 1
+    F.ensure_resident_ok()
+    assert done >= 10
+
+
+def test_kxk_resident_launches_replay_from_a_hip_graph(c_oracle):
+    """HIP-graph capture of the K x K module's scored forward (two resident launches per replay at config 3): the capture records
+    a memset of the workspace's control words in front of the launches and a constant sequence number; replays with new inputs,
+    eager launches in between — same bits, same metric sums."""
+    K, B, H, W, T = 5, 24, 228, 304, 12
+    ins = [inputs(c_oracle, B, H, W, K, False, seed=80 + k) for k in range(3)]
+    xt, gt = dev(ins[0][0], torch.float16).clone(), dev(ins[0][1], torch.float16).clone()
+    tgt = dev(np.maximum(ins[0][0] + 0.05, 0.0), torch.float16)
+    m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=None)
+    acc = pkg.evaluation.new_accumulator(DEV)
+    with torch.no_grad(), resident("on"):
+        graphed = pkg.graphs.GraphedForward(lambda: m.forward_scored(xt, gt, None, tgt, acc))
+        for k in (1, 2, 0, 1):
+            xt.copy_(dev(ins[k][0], torch.float16)); gt.copy_(dev(ins[k][1], torch.float16))
+            acc.zero_()
+            out = graphed(copy_inputs=False).clone()
+            got = acc.sum(0).cpu().numpy()
+            acc0 = pkg.evaluation.new_accumulator(DEV)
+            ref = m.forward_scored(xt, gt, None, tgt, acc0)                # eager resident launches in between
+            assert torch.equal(out, ref), k
+            assert np.allclose(got, acc0.sum(0).cpu().numpy(), rtol=1e-6)
+        graphed.synchronize()
+    F.ensure_resident_ok()

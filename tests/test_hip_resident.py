@@ -47,7 +47,10 @@ def both(g, d, s, T):
 
 SHAPES = [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (8, 352, 1216, 24), (1, 228, 304, 24), (2, 13, 20, 24),
           (5, 60, 64, 7), (2, 37, 8, 1), (1, 1, 12, 3), (3, 100, 148, 9), (1, 5, 4, 6), (30, 120, 160, 17),
-          (97, 228, 304, 24)]           # five resident launches per call (the auto policy has no cap on their number)
+          (97, 228, 304, 24),           # five resident launches per call (the auto policy has no cap on their number)
+          # single-phase launches (T <= 8) whose halo is deeper than a tile: the region must reach y0 - hyw, not stop at the
+          # previous tile's start (round 3: found by the K x K fuzz, the same origin rule lived here)
+          (1, 60, 64, 7), (1, 59, 40, 7), (2, 23, 104, 7), (1, 45, 96, 6), (4, 72, 112, 8)]
 
 
 @pytest.mark.parametrize("B,H,W,T", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
@@ -367,3 +370,30 @@ def test_many_phases_repeated_on_one_workspace(c_oracle):
     assert F._RES_SEQ_STEP >= 256
     with pytest.raises(RuntimeError, match="255 phases"):
         F.forward_resident(sets[0][0], sets[0][1][:, 0].contiguous(), None, 1100, 0, steps_per_phase=4)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_resident_equals_multi_launch(seed, c_oracle):
+    """Seeded sweep of batch / image size / step count / phase length (single-phase launches with halos deeper than a tile,
+    regions that cannot be shifted into the image, odd step counts): resident = multi-launch, bit for bit, and the oracle."""
+    rng = np.random.default_rng(5200 + seed)
+    done = 0
+    for _ in range(30):
+        B, H, W = int(rng.integers(1, 7)), int(rng.integers(1, 100)), int(4 * rng.integers(1, 40))
+        T, S = int(rng.integers(1, 26)), int(rng.choice([0, 4, 6, 8, 12]))
+        sparse = bool(rng.random() < 0.5)
+        if F.resident_plan(B, H, W, T, int(sparse), 0, S) is None:
+            continue
+        g, d, s = c_oracle.synthetic_inputs(900 + seed, B, H, W, 12, max(2, H * W // 100) if sparse else None)
+        m = pkg.CSPN_new.AffinityPropagate(T, 3)
+        with torch.no_grad():
+            with resident("off"):
+                ref = m(dev(g), dev(d), dev(s))
+            out = F.forward_resident(dev(g), dev(d)[:, 0].contiguous(), None if s is None else dev(s)[:, 0].contiguous(), T, int(sparse),
+                                     steps_per_phase=S)
+        assert torch.equal(out, ref[:, 0]), (B, H, W, T, S, sparse)
+        want = c_oracle.cspn3_forward(g, d, s, T)
+        assert rel_err(out.cpu().numpy(), want[:, 0]) <= 1e-5, (B, H, W, T, S, sparse)
+        done += 1
+    F.ensure_resident_ok()
+    assert done >= 8
