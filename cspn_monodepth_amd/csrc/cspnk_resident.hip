@@ -146,6 +146,11 @@ template <> struct StateIO<float> {
     static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 4u, o.a); st16_dev(b, e * 4u + 16u, o.b); }
 };
 
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned pk_max_f16(unsigned a, unsigned b) {
     unsigned r;
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -385,29 +390,42 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         }
     }
 
-    // ---- sparse blend operands of the owned octs: om = 1 - m, md = m * x0 (m = sign(sparse)), private LDS slots ----------
-    float* const om_lds = lds + 2 * pp;
-    float* const md_lds = om_lds + wr * wo * 8;
+    // ---- sparse blend: (1-m) u + m x0 with m = sign(sparse) (CSPN_ours.py:51-53).  1-m is 0, 1 or 2, so it is FOLDED into the
+    // taps of the owned octs once (exact: the scaled taps and every product are the unscaled ones times a power of two or
+    // zero, so sum_j ((1-m) w_j) x_j == (1-m) sum_j w_j x_j bit for bit — what cspn_prop_fused's FOLD does for fp32 taps);
+    // the steps then only add md = m * x0, kept in private LDS slots.
+    float* const md_lds = lds + 2 * pp;
     if (BLEND) {
 #pragma unroll
         for (int i = 0; i < NO; ++i) {
-            if (r0 + i < wr) {
-                const bool ok = (in_img >> i) & 1u;
-                const unsigned off = ok ? (unsigned)((yo0 + i) * W + xo) : 0u;
-                float sp[8], dv[8];
-                IO::to_f8(IO::ld_oct(spb, off), sp);
-                IO::to_f8(IO::ld_oct(x0b, off), dv);
-                float om[8], md[8];
+            const bool ok = (in_img >> i) & 1u;
+            const unsigned off = ok ? (unsigned)((yo0 + i) * W + xo) : 0u;
+            float sp[8], dv[8];
+            IO::to_f8(IO::ld_oct(spb, off), sp);
+            IO::to_f8(IO::ld_oct(x0b, off), dv);
+            float om[8], md[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float m = ok ? sgnf(sp[e]) : 0.f;
-                    om[e] = 1.f - m;
-                    md[e] = m * (ok ? dv[e] : 0.f);
-                }
-                float* po = om_lds + ((r0 + i) * wo + sx) * 8;
+            for (int e = 0; e < 8; ++e) {
+                const float m = ok ? sgnf(sp[e]) : 0.f;
+                om[e] = 1.f - m;
+                md[e] = m * (ok ? dv[e] : 0.f);
+            }
+            if constexpr (PK) {
+                unsigned omp[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) omp[q] = pack_h2(om[2 * q], om[2 * q + 1]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) set_comp(wpk[PK ? i : 0][PK ? c : 0], q, pk_mul_f16(comp(wpk[PK ? i : 0][PK ? c : 0], q), omp[q]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wf[PK ? 0 : i][PK ? 0 : c][e] *= om[e];
+            }
+            if (r0 + i < wr) {
                 float* pm = md_lds + ((r0 + i) * wo + sx) * 8;
-                *reinterpret_cast<float4*>(po) = make_float4(om[0], om[1], om[2], om[3]);
-                *reinterpret_cast<float4*>(po + 4) = make_float4(om[4], om[5], om[6], om[7]);
                 *reinterpret_cast<float4*>(pm) = make_float4(md[0], md[1], md[2], md[3]);
                 *reinterpret_cast<float4*>(pm + 4) = make_float4(md[4], md[5], md[6], md[7]);
             }
@@ -549,12 +567,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                 for (int e = 0; e < 8; ++e) u[e] = acc[i][e];
                 if (BLEND) {
                     const int q = (min(r0 + i, wr - 1) * wo + sx) * 8;
-                    const float4 oa = *reinterpret_cast<const float4*>(om_lds + q), ob = *reinterpret_cast<const float4*>(om_lds + q + 4);
                     const float4 ma = *reinterpret_cast<const float4*>(md_lds + q), mb = *reinterpret_cast<const float4*>(md_lds + q + 4);
-                    const float om[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
                     const float md[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) u[e] = om[e] * u[e] + md[e];       // (1-m) u + m x0   CSPN_ours.py:51-53
+                    for (int e = 0; e < 8; ++e) u[e] += md[e];                     // (1-m) lives in the taps: + m x0
                 }
                 if (!CLEAN) {
 #pragma unroll
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                 }
             }
         }
-        float* part = lds + 2 * pp + (BLEND ? 2 : 0) * wr * wo * 8;
+        float* part = lds + 2 * pp + (BLEND ? 1 : 0) * wr * wo * 8;
         const int wave = tid >> 6, lane = tid & 63;
         __syncthreads();
 #pragma unroll
@@ -715,7 +731,7 @@ int kres_row_stride(int wo, int no) {
 }
 
 size_t kres_lds_bytes(int dr, int ls, int wr, int wo, int blend) {
-    return ((size_t)2 * dr * ls + (size_t)(blend ? 2 : 0) * wr * wo * 8 + 16 * 10) * sizeof(float);
+    return ((size_t)2 * dr * ls + (size_t)(blend ? 1 : 0) * wr * wo * 8 + 16 * 10) * sizeof(float);
 }
 
 bool kregions_inside_image(const KGeom& g, int H, int W, int T) {
@@ -779,6 +795,9 @@ bool kgeom_fill(int K, int gdt, int H, int W, int T, int blend, int ncu, int B, 
     const double taps = (double)(K * K - 1) / 24.0 * (gdt == CSPN_F32 ? 0.8 : 1.0);
     const double pen = kregions_inside_image(*g, H, W, T) ? 1.0 : 1.1;
     g->cost = launches * (3.0 + 3.3 * taps * per_oct + T * (0.5 * taps * per_oct * pen + 0.08) + (phases - 1) * 3.2);
+    // three octs of fp32 taps per thread is a 256-VGPR instance with 44-78 spilled registers; with the blend's extra work in
+    // the step it loses to two launches of one oct on 768 threads (config unet_ours, sparse: 87 vs 78.5 us; without: 67 vs 71)
+    if (gdt == CSPN_F32 && no == 3 && blend) g->cost *= 1.25;
     return true;
 }
 

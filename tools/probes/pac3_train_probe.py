@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Developer probe: forward + backward of CSPN_ours at the reference model's configuration (unet_ours: K = 3, 8-channel fp32
+guidance, 24 steps) next to CSPN_new at the same size."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch                                         # noqa: E402
+import cspn_monodepth_amd as pkg                     # noqa: E402
+
+for B in (24, 3):
+    H, W, T = 228, 304, 24
+    d = (torch.rand(B, 1, H, W, device="cuda") * 10).requires_grad_(True)
+    s = d.detach() * (torch.rand_like(d) < 0.007)
+    cot = torch.randn(B, 1, H, W, device="cuda")
+    for name, C, mk, call in (("CSPN_ours K=3", 8, lambda: pkg.CSPN_ours.AffinityPropagate(T), lambda m, g: m(d, g, sparse_depth=s)),
+                              ("CSPN_new  3x3", 12, lambda: pkg.CSPN_new.AffinityPropagate(T, 3), lambda m, g: m(g, d, s))):
+        g = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+        m = mk()
+
+        def it():
+            g.grad = None
+            d.grad = None
+            call(m, g).backward(cot)
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            it()
+        torch.cuda.synchronize()
+        fb = (time.perf_counter() - t0) / 30 * 1e6
+        with torch.no_grad():
+            for _ in range(5):
+                call(m, g)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                call(m, g)
+            torch.cuda.synchronize()
+            fw = (time.perf_counter() - t0) / 50 * 1e6
+        print("B=%d %s: inference %.1f us, forward + backward %.1f us" % (B, name, fw, fb))
