@@ -797,7 +797,7 @@ bool kgeom_fill(int K, int gdt, int H, int W, int T, int blend, int ncu, int B, 
     g->cost = launches * (3.0 + 3.3 * taps * per_oct + T * (0.5 * taps * per_oct * pen + 0.08) + (phases - 1) * 3.2);
     // three octs of fp32 taps per thread is a 256-VGPR instance with 44-78 spilled registers; with the blend's extra work in
     // the step it loses to two launches of one oct on 768 threads (config unet_ours, sparse: 87 vs 78.5 us; without: 67 vs 71)
-    if (gdt == CSPN_F32 && no == 3 && blend) g->cost *= 1.25;
+    if (gdt == CSPN_F32 && no == 3 && blend) g->cost *= 1.4;
     return true;
 }
 
