@@ -152,8 +152,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // launch — launches on a workspace never overlap — and, in the last launch of a call, stores `seq` to the second host
     // word.  A host that polls that word (no HIP call, no event on the stream) knows the call has finished and that
     // host_err[0] is final: a workgroup that gave up stored the error, fenced at system scope, and only then counted out.
+    // Only the training-form launches (MODE 2 / 3) report: their reader is the end-of-backward check, inference results are
+    // checked where the host synchronises anyway.  (Same-box A/B at config 2: the returning atomic at the end of every
+    // workgroup costs the inference launch 0.6 us; counting out at the start of the last phase instead — a tile that waits
+    // for nobody any more cannot time out — costs 1.3 us, the atomic then sits in the register-bound loop nest.)
     auto count_out = [&]() {
-        if (tid == 0) {
+        if (HIST && tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old + 1u == gridDim.x) {
                 __hip_atomic_store(a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -15,7 +15,7 @@
 //     of the neighbouring octs: no DPP, no divergent patch blocks (the step is VALU-bound on its 8 (K*K-1) FMAs per oct);
 //   * between phases the tiles exchange borders through a global plane with device-scope (sc1) stores / loads and per-tile
 //     phase flags, exactly as cspn3_resident (cspn_resident.hip) — same workspace layout, same bounded wait, same sticky
-//     error + completion words.
+//     error word.
 // State dtype: the depth planes (x0, sparse, out, target, exchange) are fp16 or fp32.  With fp16 state the multi-launch
 // schedule rounds the state to half between launches; the resident launch rounds it at the phase boundaries, so with
 // steps_per_phase = steps_per_launch the two schedules produce the same bits (tests/test_hip_kres.py).
@@ -230,15 +230,8 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     int n_stamp = 0;
     auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
     stamp();
-    auto count_out = [&]() {                       // see cspn3_resident: completion word for host-side polling
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1u == gridDim.x) {
-                __hip_atomic_store(a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.host_err && a.last_chunk) __hip_atomic_store(a.host_err + 1, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    };
+    // (no completion word: these launches are inference-only; their results are checked where the host synchronises —
+    // functional.ensure_resident_ok — and only the training-form launches of cspn3_resident report to the end-of-backward check)
 
     const ST* __restrict__ x0b = kuniform_ptr(static_cast<const ST*>(a.x0) + (size_t)b * HW);
     const ST* __restrict__ spb = BLEND ? kuniform_ptr(static_cast<const ST*>(a.sparse) + (size_t)b * HW) : nullptr;
@@ -643,7 +636,6 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
 #pragma unroll
                 for (int i = 0; i < NO; ++i)
                     if ((interior >> i) & 1u) IO::st_oct(outb, (unsigned)((yo0 + i) * W + xo), o);
-                count_out();
                 return;
             }
         }
@@ -689,7 +681,6 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         }
     }
     stamp();                                   // epilogue done
-    count_out();
 }
 
 // ------------------------------------------------------------------------------------------------ host side

@@ -684,7 +684,7 @@ class _ResidentCheckpoint(object):
         check_resident_errors(self.dev)
 
 
-def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None):
+def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None, reports_done=False):
     """The host protocol of every resident launch on `dev`: one at a time per device (lock; a launch from another stream
     first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence number,
     the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call.
@@ -734,7 +734,8 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
                 st["host_err_np"][1] = 0
             seq = st["seq"]
             st["seq"] = seq + _RES_SEQ_STEP
-            st["last_seq"] = seq
+            if reports_done:                            # training-form launches store `seq` to the completion word
+                st["last_seq"] = seq
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
@@ -768,7 +769,7 @@ def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
                                            int(valid_w), int(T), int(sparse_f32 is not None),
                                            None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True)
     _lib.check(ok, "cspn3_transposed_resident")
     return ghist
 
@@ -805,7 +806,7 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
                                         int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                         None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history))
     _lib.check(ok, "cspn3_forward_resident")
     if keep_history:
         return hist[int(T) - 1], hist, w8, S_out

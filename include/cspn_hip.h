@@ -235,9 +235,9 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * plane) — and the caller must check the word before trusting the result (functional.ensure_resident_ok).
  *
  * host_err_or_null: TWO host-mapped 32-bit words (pinned host memory the device can write): [0] receives 1 on a time-out;
- * [1] receives `seq` when the last launch of the call has finished — the last workgroup to count itself out (status word
- * 2 of the workspace) stores it — so a host can learn "this call is complete and host_err[0] is final" by polling host
- * memory, without a HIP call or an event on the stream (functional._ResidentCheckpoint: the end-of-backward check).
+ * [1] receives `seq` when the last launch of a TRAINING-form call (history != NULL) or of cspn3_transposed_resident has
+ * finished — the last workgroup to count itself out (status word 2 of the workspace) stores it — so a host can learn
+ * "this call is complete and host_err[0] is final" by polling host memory, without a HIP call or an event on the stream (functional._ResidentCheckpoint: the end-of-backward check).
  *
  * work: cspn3_resident_workspace_bytes(B,H,W) bytes, ZERO-initialised once by the caller, then only ever passed to this
  * entry.  seq: any value in [1, 2^31-256] that grows by at least 256 from one call on the same workspace to the next
