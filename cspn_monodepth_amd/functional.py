@@ -1084,7 +1084,7 @@ class PACFunction(torch.autograd.Function):
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         sp = None if sp is None else sp.to(sdt)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        if not need_grad and CX == 1:
+        if not need_grad and CX == 1 and not valid_w:       # (row padding — W_valid — is the multi-launch kernels' business)
             g = guided if guided.is_contiguous() else guided.contiguous()
             d0 = _plane(x, B, H, W, "x").to(sdt)
             if pac_resident_supported(g, d0, sp, prop_time, plan) is not None:

@@ -293,3 +293,18 @@ def test_kxk_resident_launches_replay_from_a_hip_graph(c_oracle):
             assert np.allclose(got, acc0.sum(0).cpu().numpy(), rtol=1e-6)
         graphed.synchronize()
     F.ensure_resident_ok()
+
+
+def test_odd_widths_stay_on_the_multi_launch_schedule(c_oracle):
+    """W = 37 is padded to 40 = 5 octs by the module (row padding, W_valid): the resident launches know nothing of W_valid, so the
+    call must not reach them (regression: round 3, found by tests/test_hip_fuzz.py) — and the result must match the oracle."""
+    K, B, H, W, T = 5, 1, 6, 37, 3
+    x, gd, s = inputs(c_oracle, B, H, W, K, True, seed=69)
+    want = c_oracle.pac_forward(x, gd, s, T)
+    with torch.no_grad(), resident("on"):
+        out = pkg.CSPN_ours.AffinityPropagate(T)(dev(x), dev(gd), sparse_depth=dev(s))
+        acc = pkg.evaluation.new_accumulator(DEV)
+        out2 = pkg.CSPN_ours.AffinityPropagate(T).forward_scored(dev(x), dev(gd), dev(s), dev(np.abs(x) + 0.1), acc)
+    scale = float(np.abs(want).max())
+    assert float(np.abs(out.cpu().numpy() - want).max()) <= 1e-5 * scale
+    assert torch.equal(out, out2)
