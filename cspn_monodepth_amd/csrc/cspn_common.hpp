@@ -16,6 +16,10 @@ namespace cspn_detail {
 // thread-local message of the last failing entry point on this thread (defined in cspn_metrics.hip)
 int fail(const char* fmt, ...);
 const char* last_error();
+// cspn_resident.hip: the K = 3 softmax-weight form of the quad-based resident kernel (used by cspnk_forward_resident)
+int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* work, unsigned seq, unsigned* host_err,
+                      int B, int H, int W, int T, int blend, const void* target, double* acc, int nslots,
+                      const cspn_resident_plan* plan, void* stream);
 }  // namespace cspn_detail
 
 namespace {

@@ -121,8 +121,12 @@ constexpr int RES_PP = 16352;
 // instances their spill-free hot loop.
 // MODE 0: inference; 1: inference + fused depth metrics; 2: training forward — every step's state goes to its history
 // plane and the weights + S are published once (what cspn3_propagate_from_guidance hands the backward).
-template <int NQ, int NTHREADS, int BLEND, int MODE, int CLEAN>
+// PAC = 1: the weights are the softmax over the 8 guidance channels at the CENTRE pixel (tap j = channel j: the K = 3 case of
+// CSPN_ours.py:35-41) instead of the neighbour-indexed, sum-normalised gates of CSPN_new — everything after the derive (steps,
+// exchange, blend, metrics) is the same recurrence.  Inference only (MODE 0 / 1).
+template <int NQ, int NTHREADS, int BLEND, int MODE, int CLEAN, int PAC = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
+    static_assert(!PAC || MODE < 2, "the softmax-weight form is inference only");
     constexpr int R = 1, NT = 8, WIN = 6;
     // MODE 3: the backward's reverse sweep  G_t = stencil^T((1-m) G_{t+1})  as the same recurrence on the TRANSPOSED taps:
     // tap j = w_{7-j}[p + off_j], gathered from the forward tap volume [B,8,H,W] (a.g) exactly like channel 7-j of the
@@ -264,14 +268,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int lin = j < 4 ? j : j + 1;
-            const int d = lin / 3;
-            const float4 v = ld4(at32(gq, (unsigned)(7 - j) * ucs + orow[d]));
+            const int d = PAC ? 1 : lin / 3;                          // PAC: channel j at the quad itself
+            const float4 v = ld4(at32(gq, (unsigned)(PAC ? j : 7 - j) * ucs + orow[d]));
             wreg[i][j][0] = rokv[d] ? v.x : 0.f; wreg[i][j][1] = rokv[d] ? v.y : 0.f;
             wreg[i][j][2] = rokv[d] ? v.z : 0.f; wreg[i][j][3] = rokv[d] ? v.w : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 6; ++t) edge[i][t] = 0.f;
-        if (fix_left || fix_right) {
+        if (!PAC && (fix_left || fix_right)) {
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const bool lft = t < 3;
@@ -328,6 +332,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             return ok && row >= 0 && row < H && (lft ? xq - 1 >= 0 : xq + 4 < W);
         };
         const unsigned off = ok ? (unsigned)((yq0 + i) * W + xq) : 0u;
+        if constexpr (PAC) {
+            // softmax over the 8 channels per pixel: the arithmetic of cspn_pac_prepare_kernel<3, float, float> (maximum,
+            // two-piece exponential, sum in channel order, one refined reciprocal), so the taps are those of the prepared volume
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mx = fmaxf(mx, wreg[i][j][e]);
+                float den = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { wreg[i][j][e] = softmax_exp<float>(wreg[i][j][e] - mx); den += wreg[i][j][e]; }
+                const float inv = reciprocal_refined(den);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? softmax_weight<float>(wreg[i][j][e], inv) : 0.f;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int lin = j < 4 ? j : j + 1;
@@ -818,9 +839,9 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
     return found;
 }
 
-template <int NQ, int BLEND, int MODE, int CLEAN>
+template <int NQ, int BLEND, int MODE, int CLEAN, int PAC = 0>
 int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, MODE, CLEAN>;
+    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, MODE, CLEAN, PAC>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -835,6 +856,10 @@ int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream
 
 template <int NQ, int CLEAN>
 int launch_resident_c(const ResArgs& a, int grid, size_t lds, int blend, int mode, hipStream_t st) {
+    if (mode >= 4) {          // softmax-weight (PAC) forms of MODE 0 / 1
+        if (blend) return mode == 5 ? launch_resident_inst<NQ, 1, 1, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0, CLEAN, 1>(a, grid, lds, st);
+        return mode == 5 ? launch_resident_inst<NQ, 0, 1, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0, CLEAN, 1>(a, grid, lds, st);
+    }
     if (mode == 3) return blend ? launch_resident_inst<NQ, 1, 3, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 3, CLEAN>(a, grid, lds, st);
     if (blend) {
         if (mode == 2) return launch_resident_inst<NQ, 1, 2, CLEAN>(a, grid, lds, st);
@@ -855,7 +880,7 @@ namespace {
 int resident_launch(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out, void* history,
                     void* w8_out, float* s_out, void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid,
                     int T, int blend, const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
-                    cspn_stream_t stream, bool transposed);
+                    cspn_stream_t stream, bool transposed, bool pac = false);
 }
 
 extern "C" {
@@ -903,13 +928,24 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
 
 }  // extern "C"
 
+namespace cspn_detail {
+// K = 3 softmax (CSPN_ours) forward with fp32 guidance [B,8,H,W] on the quad kernel: called by cspnk_forward_resident
+// (cspnk_resident.hip), whose oct kernel holds only two or three octs of fp32 taps per thread.
+int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* work, unsigned seq, unsigned* host_err,
+                      int B, int H, int W, int T, int blend, const void* target, double* acc, int nslots,
+                      const cspn_resident_plan* plan, cspn_stream_t stream) {
+    return resident_launch(guided, (long)8 * H * W, (long)H * W, x0, sparse, out, nullptr, nullptr, nullptr, work, seq, host_err, B, H, W, 0, T,
+                           blend, target, acc, nslots, plan, stream, /*transposed=*/false, /*pac=*/true);
+}
+}  // namespace cspn_detail
+
 namespace {
 
 int resident_launch(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out,
                     void* history, void* w8_out, float* s_out,
                     void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid, int T, int blend,
                     const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
-                    cspn_stream_t stream, bool transposed) {
+                    cspn_stream_t stream, bool transposed, bool pac) {
     if (!guidance || !d0 || !work || B <= 0 || H <= 0 || W <= 0 || T < 1 || (!out && !history))
         return fail("cspn3_forward_resident: bad arguments");
     if (!transposed && history && (!w8_out || !s_out || target || acc || !aligned16(history) || !aligned16(w8_out) || !aligned16(s_out)))
@@ -968,7 +1004,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         return fail("cspn3_forward_resident: workspace too small for %d tiles", B * g.tiles_x * g.tiles_y);
     a.host_err = host_err;
     a.hist = static_cast<float*>(history); a.w_out = static_cast<float*>(w8_out); a.s_out = s_out;
-    const int mode = transposed ? 3 : (history ? 2 : (acc ? 1 : 0));
+    if (pac && (transposed || history)) return fail("cspn3_forward_resident: the softmax-weight form is inference only");
+    const int mode = transposed ? 3 : (history ? 2 : (acc ? 1 : 0)) + (pac ? 4 : 0);
     a.seq = seq;
     a.target = static_cast<const float*>(target); a.macc = acc; a.nslots = nslots;
     a.B = B; a.H = H; a.W = W; a.Wv = (W_valid > 0 && W_valid < W) ? W_valid : W; a.T = T; a.S = g.S;

@@ -201,7 +201,8 @@ constexpr int KRES_THREADS = 512;        // default workgroup; 768 threads (3 wa
 // (sy, sx) reads E[sx], O[sx] with ds_read_b128 (consecutive lanes = consecutive 16-byte slots: conflict-free) and the R
 // pixels left / right of its oct as the tail of O[sx-1] / the head of E[sx+1].
 // GT = the guidance dtype: __half -> taps packed two pixels per register (v_fma_mix_f32); float -> fp32 taps, 8 (K*K-1) registers
-// per oct, plain v_fma_f32 — the configuration the reference's own model runs (unet_ours: 8-channel fp32 guidance, K = 3).
+// per oct, plain v_fma_f32 (launched for K = 5 only: K = 3 in fp32 — the reference model's own configuration — runs on the quad
+// kernel of cspn_resident.hip in its softmax-weight form, see cspnk_resident_plan).
 template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH = KRES_THREADS, typename GT = __half>
 __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs a) {
     constexpr int R = K / 2, NT = K * K - 1;
@@ -751,7 +752,7 @@ bool kgeom_fill(int K, int gdt, int H, int W, int T, int blend, int ncu, int B, 
     const int R = K / 2;
     if (threads != 512 && threads != 768) return false;
     int max_no = threads == 768 ? (K == 5 ? 1 : 2) : (K == 5 ? KRES_MAX_NO_K5 : KRES_MAX_NO_K3);
-    if (gdt == CSPN_F32) max_no = K == 3 ? (threads == 768 ? 1 : 3) : (threads == 768 ? 0 : 1);   // fp32 taps: 64 / 192 registers per oct
+    if (gdt == CSPN_F32) max_no = (K == 5 && threads == 512) ? 1 : 0;       // fp32 taps: 192 registers per oct at K = 5 (K = 3: quad kernel)
     const int hyw = (Se - 1) * R, hxw = round_up8((Se - 1) * R);
     const int phases = ceil_div(T, Se);
     if (phases > 1 && (Se & 1)) return false;          // every phase must start in buffer 0
@@ -786,9 +787,6 @@ bool kgeom_fill(int K, int gdt, int H, int W, int T, int blend, int ncu, int B, 
     const double taps = (double)(K * K - 1) / 24.0 * (gdt == CSPN_F32 ? 0.8 : 1.0);
     const double pen = kregions_inside_image(*g, H, W, T) ? 1.0 : 1.1;
     g->cost = launches * (3.0 + 3.3 * taps * per_oct + T * (0.5 * taps * per_oct * pen + 0.08) + (phases - 1) * 3.2);
-    // three octs of fp32 taps per thread is a 256-VGPR instance with 44-78 spilled registers; with the blend's extra work in
-    // the step it loses to two launches of one oct on 768 threads (config unet_ours, sparse: 87 vs 78.5 us; without: 67 vs 71)
-    if (gdt == CSPN_F32 && no == 3 && blend) g->cost *= 1.4;
     return true;
 }
 
@@ -860,15 +858,10 @@ int klaunch_k(const KResArgs& a, int no, int threads, int grid, size_t lds, int 
     return fail("cspnk_forward_resident: no instance for K=%d with %d octs per thread", K, no);
 }
 
-// fp32 guidance (fp32 depth planes): K = 3 with one or two octs per thread, K = 5 with one
+// fp32 guidance (fp32 depth planes) on the oct kernel: K = 5, one oct per thread (192 tap registers); K = 3 goes to the quad kernel
 template <int K>
 int klaunch_f32(const KResArgs& a, int no, int threads, int grid, size_t lds, int blend, int score, bool clean, hipStream_t st) {
     if (threads == 512 && no == 1) return klaunch_no<K, 1, float, 512, float>(a, grid, lds, blend, score, clean, st);
-    if constexpr (K == 3) {
-        if (threads == 512 && no == 2) return klaunch_no<K, 2, float, 512, float>(a, grid, lds, blend, score, clean, st);
-        if (threads == 512 && no == 3) return klaunch_no<K, 3, float, 512, float>(a, grid, lds, blend, score, clean, st);
-        if (threads == 768 && no == 1) return klaunch_no<K, 1, float, 768, float>(a, grid, lds, blend, score, clean, st);
-    }
     return fail("cspnk_forward_resident: no fp32-guidance instance for K=%d with %d octs per thread on %d threads", K, no, threads);
 }
 
@@ -882,6 +875,13 @@ int cspnk_resident_plan(int K, int g_dtype, int B, int H, int W, int T, int blen
     if (K != 3 && K != 5) return fail("cspnk_resident_plan: K=%d (3 or 5)", K);
     if (n_cu <= 0) n_cu = kcu_count();
     if (n_cu <= 0) return fail("cspnk_resident_plan: no device (pass n_cu > 0 to plan without one)");
+    if (K == 3 && g_dtype == CSPN_F32) {
+        // fp32 taps at K = 3 (the unet_ours configuration): the quad kernel of cspn_resident.hip in its softmax-weight form —
+        // five quads of taps per thread, all 24 frames of a 228 x 304 batch in one launch; the oct kernel held at most three
+        // octs of fp32 taps, with spills (65-78 us against 46).  `threads` is ignored (that kernel has 512).
+        out->threads = 0;
+        return cspn3_resident_plan(B, H, W, T, blend, n_cu, out);
+    }
     KGeom g;
     if (T < 1 || !kres_geometry(K, g_dtype, B, H, W, T, blend, n_cu, out->steps_per_phase, out->threads, &g))
         return fail("cspnk_resident_plan: no resident tiling for K=%d B=%d %dx%d T=%d on %d CUs (W %% 8 == 0 needed)", K, B, H, W, T, n_cu);
@@ -920,6 +920,11 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
     KGeom g;
     cspn_resident_plan rp{};
     if (plan) rp = *plan;
+    if (K == 3 && g_dtype == CSPN_F32) {       // see cspnk_resident_plan
+        cspn_resident_plan qp = rp;
+        qp.threads = 0;
+        return cspn_detail::resident_pac3_f32(guided, x0, sparse, out, work, seq, host_err, B, H, W, T, blend, target, acc, nslots, &qp, stream);
+    }
     if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
         const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
         if (!kgeom_fill(K, g_dtype, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
@@ -952,8 +957,7 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
         if (g_dtype == CSPN_F32) {
-            ok = K == 5 ? klaunch_f32<5>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st)
-                        : klaunch_f32<3>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
+            ok = klaunch_f32<5>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
         } else if (K == 5) {
             ok = state_dtype == CSPN_F16 ? klaunch_k<5, __half>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st)
                                          : klaunch_k<5, float>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);

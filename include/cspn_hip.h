@@ -283,7 +283,8 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
  * centre tap :37-39, prop_time x { pac.conv2d :49 -> base/pac.py:89-92, sparse blend :51-53 }) as weight-resident launches:
  * `guided` [B, K*K-1, H, W] (g_dtype fp16 or fp32) is read ONCE, the softmax weights stay in registers for all T steps —
  * fp16 guidance: taps packed two pixels per register; fp32 guidance (fp32 depth planes only; what the reference's unet_ours
- * feeds: 8-channel fp32, K = 3): fp32 taps, the 1e-5 parity of the multi-launch fp32 path — no tap volume is written
+ * feeds: 8-channel fp32, K = 3 — served by cspn3_resident's kernel in its softmax-weight form, `threads` ignored): fp32
+ * taps, the 1e-5 parity of the multi-launch fp32 path — no tap volume is written
  * (cspn_pac_prepare + cspn_propagate move 4.8x the compulsory bytes at BASELINE config 3).  K = 3 or 5; W % 8 == 0 (whole octs).  x0 / sparse / out / target are [B,H,W] planes of `state_dtype` (CSPN_F16 or CSPN_F32); with fp16
  * planes the state is rounded to half at every phase boundary — exactly where cspn_propagate with steps_per_launch =
  * steps_per_phase rounds it between launches, so the two schedules agree bit for bit (weights: same softmax arithmetic as

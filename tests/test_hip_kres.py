@@ -52,8 +52,9 @@ def multi_launch(x, gd, s, T, S, state):
     if S * (K // 2) > 8:       # deep halos: the engine's partial-plan search has no tiling for them; any fitting tiling gives the same bits
         R = K // 2
         hy, hx = (S - 1) * R, -(-(S - 1) * R // 4) * 4
-        rows = 3 * (256 // ((32 + 2 * hx) // 4)) - 2 * hy
-        plan = dict(steps_per_launch=S, tile_w=32, tile_h=max(1, min(rows, gd.shape[2])), quads_per_thread=3 if K == 5 else 2, threads=256)
+        nq = 3 if K == 5 else 2
+        rows = nq * (256 // ((32 + 2 * hx) // 4)) - 2 * hy
+        plan = dict(steps_per_launch=S, tile_w=32, tile_h=max(1, min(rows, gd.shape[2])), quads_per_thread=nq, threads=256)
     m = pkg.CSPN_ours.AffinityPropagate(T, plan=plan, state_dtype=state)
     with torch.no_grad(), resident("off"):
         return m(x, gd, sparse_depth=s)
