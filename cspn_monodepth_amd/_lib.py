@@ -28,7 +28,7 @@ EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
     "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn_propagate_transposed", "cspn3_propagate_from_guidance",
     "cspn_transpose_weights", "cspn3_resident_plan", "cspn3_resident_workspace_bytes", "cspn3_forward_resident", "cspn3_transposed_resident",
-    "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident",
+    "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident", "cspnk_forward_resident_history",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
     "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
@@ -146,6 +146,8 @@ def _declare(lib):
     lib.cspnk_resident_workspace_bytes.restype = cs
     lib.cspnk_forward_resident.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, vp, vp, ci,
                                            ctypes.POINTER(cspn_resident_plan), vp]
+    lib.cspnk_forward_resident_history.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci,
+                                                   ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]

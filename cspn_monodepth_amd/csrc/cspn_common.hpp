@@ -17,9 +17,9 @@ namespace cspn_detail {
 int fail(const char* fmt, ...);
 const char* last_error();
 // cspn_resident.hip: the K = 3 softmax-weight form of the quad-based resident kernel (used by cspnk_forward_resident)
-int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* work, unsigned seq, unsigned* host_err,
-                      int B, int H, int W, int T, int blend, const void* target, double* acc, int nslots,
-                      const cspn_resident_plan* plan, void* stream);
+int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* history, void* wk_out, void* work,
+                      unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend, const void* target, double* acc,
+                      int nslots, const cspn_resident_plan* plan, void* stream);
 }  // namespace cspn_detail
 
 namespace {

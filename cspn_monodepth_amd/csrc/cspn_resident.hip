@@ -123,10 +123,11 @@ constexpr int RES_PP = 16352;
 // plane and the weights + S are published once (what cspn3_propagate_from_guidance hands the backward).
 // PAC = 1: the weights are the softmax over the 8 guidance channels at the CENTRE pixel (tap j = channel j: the K = 3 case of
 // CSPN_ours.py:35-41) instead of the neighbour-indexed, sum-normalised gates of CSPN_new — everything after the derive (steps,
-// exchange, blend, metrics) is the same recurrence.  Inference only (MODE 0 / 1).
+// exchange, blend, metrics, history planes) is the same recurrence.  MODE 2 publishes the softmax taps as the [B,8,H,W] volume the
+// backward streams (no S: the softmax backward does not need one); the reverse sweep is the plain MODE 3 on that volume.
 template <int NQ, int NTHREADS, int BLEND, int MODE, int CLEAN, int PAC = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
-    static_assert(!PAC || MODE < 2, "the softmax-weight form is inference only");
+    static_assert(!PAC || MODE <= 2, "the softmax-weight form has no transposed sweep of its own (the published volume feeds MODE 3)");
     constexpr int R = 1, NT = 8, WIN = 6;
     // MODE 3: the backward's reverse sweep  G_t = stencil^T((1-m) G_{t+1})  as the same recurrence on the TRANSPOSED taps:
     // tap j = w_{7-j}[p + off_j], gathered from the forward tap volume [B,8,H,W] (a.g) exactly like channel 7-j of the
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? softmax_weight<float>(wreg[i][j][e], inv) : 0.f;
             }
+            if (MODE == 2 && ((interior >> i) & 1u)) store_taps_quad<NT>(a.w_out + (size_t)b * NT * HW, off, HW, wreg[i]);
             continue;
         }
 #pragma unroll
@@ -856,7 +858,8 @@ int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream
 
 template <int NQ, int CLEAN>
 int launch_resident_c(const ResArgs& a, int grid, size_t lds, int blend, int mode, hipStream_t st) {
-    if (mode >= 4) {          // softmax-weight (PAC) forms of MODE 0 / 1
+    if (mode >= 4) {          // softmax-weight (PAC) forms of MODE 0 / 1 / 2
+        if (mode == 6) return blend ? launch_resident_inst<NQ, 1, 2, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 2, CLEAN, 1>(a, grid, lds, st);
         if (blend) return mode == 5 ? launch_resident_inst<NQ, 1, 1, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0, CLEAN, 1>(a, grid, lds, st);
         return mode == 5 ? launch_resident_inst<NQ, 0, 1, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0, CLEAN, 1>(a, grid, lds, st);
     }
@@ -931,10 +934,10 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
 namespace cspn_detail {
 // K = 3 softmax (CSPN_ours) forward with fp32 guidance [B,8,H,W] on the quad kernel: called by cspnk_forward_resident
 // (cspnk_resident.hip), whose oct kernel holds only two or three octs of fp32 taps per thread.
-int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* work, unsigned seq, unsigned* host_err,
-                      int B, int H, int W, int T, int blend, const void* target, double* acc, int nslots,
-                      const cspn_resident_plan* plan, cspn_stream_t stream) {
-    return resident_launch(guided, (long)8 * H * W, (long)H * W, x0, sparse, out, nullptr, nullptr, nullptr, work, seq, host_err, B, H, W, 0, T,
+int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* history, void* wk_out, void* work,
+                      unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend, const void* target, double* acc,
+                      int nslots, const cspn_resident_plan* plan, cspn_stream_t stream) {
+    return resident_launch(guided, (long)8 * H * W, (long)H * W, x0, sparse, out, history, wk_out, nullptr, work, seq, host_err, B, H, W, 0, T,
                            blend, target, acc, nslots, plan, stream, /*transposed=*/false, /*pac=*/true);
 }
 }  // namespace cspn_detail
@@ -948,7 +951,7 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
                     cspn_stream_t stream, bool transposed, bool pac) {
     if (!guidance || !d0 || !work || B <= 0 || H <= 0 || W <= 0 || T < 1 || (!out && !history))
         return fail("cspn3_forward_resident: bad arguments");
-    if (!transposed && history && (!w8_out || !s_out || target || acc || !aligned16(history) || !aligned16(w8_out) || !aligned16(s_out)))
+    if (!transposed && history && (!w8_out || (!pac && !s_out) || target || acc || !aligned16(history) || !aligned16(w8_out) || (s_out && !aligned16(s_out))))
         return fail("cspn3_forward_resident: the training form (history) needs w8_out and s_out, 16-byte aligned, and no scoring");
     if (!history && (w8_out || s_out)) return fail("cspn3_forward_resident: w8_out / s_out are outputs of the training form (history)");
     if (transposed && !aligned16(history)) return fail("cspn3_transposed_resident: history must be 16-byte aligned");
@@ -1004,7 +1007,7 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         return fail("cspn3_forward_resident: workspace too small for %d tiles", B * g.tiles_x * g.tiles_y);
     a.host_err = host_err;
     a.hist = static_cast<float*>(history); a.w_out = static_cast<float*>(w8_out); a.s_out = s_out;
-    if (pac && (transposed || history)) return fail("cspn3_forward_resident: the softmax-weight form is inference only");
+    if (pac && transposed) return fail("cspn3_forward_resident: the softmax-weight form has no transposed sweep (use cspn3_transposed_resident on the volume)");
     const int mode = transposed ? 3 : (history ? 2 : (acc ? 1 : 0)) + (pac ? 4 : 0);
     a.seq = seq;
     a.target = static_cast<const float*>(target); a.macc = acc; a.nslots = nslots;

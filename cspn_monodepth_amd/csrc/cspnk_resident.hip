@@ -923,7 +923,8 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
     if (K == 3 && g_dtype == CSPN_F32) {       // see cspnk_resident_plan
         cspn_resident_plan qp = rp;
         qp.threads = 0;
-        return cspn_detail::resident_pac3_f32(guided, x0, sparse, out, work, seq, host_err, B, H, W, T, blend, target, acc, nslots, &qp, stream);
+        return cspn_detail::resident_pac3_f32(guided, x0, sparse, out, nullptr, nullptr, work, seq, host_err, B, H, W, T, blend, target, acc,
+                                              nslots, &qp, stream);
     }
     if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
         const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
@@ -968,6 +969,21 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         if (!ok) return 0;
     }
     return 1;
+}
+
+int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const void* x0, const void* sparse, void* history, void* wk_out,
+                                   void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend,
+                                   const cspn_resident_plan* plan, cspn_stream_t stream) {
+    if (!guided || !x0 || !history || !wk_out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1)
+        return fail("cspnk_forward_resident_history: bad arguments");
+    if (K != 3 || g_dtype != CSPN_F32)
+        return fail("cspnk_forward_resident_history: the training form exists for K = 3 with fp32 guidance (K=%d, dtype %d: use "
+                    "cspn_pac_prepare + cspn_propagate with history)", K, g_dtype);
+    cspn_resident_plan qp{};
+    if (plan) qp = *plan;
+    qp.threads = 0;
+    return cspn_detail::resident_pac3_f32(guided, x0, sparse, nullptr, history, wk_out, work, seq, host_err, B, H, W, T, blend, nullptr, nullptr,
+                                          0, &qp, stream);
 }
 
 }  // extern "C"

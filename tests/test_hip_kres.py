@@ -309,3 +309,38 @@ def test_odd_widths_stay_on_the_multi_launch_schedule(c_oracle):
     scale = float(np.abs(want).max())
     assert float(np.abs(out.cpu().numpy() - want).max()) <= 1e-5 * scale
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 228, 304, 24), (2, 37, 40, 7), (1, 352, 1216, 24), (5, 60, 64, 9)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_k3_fp32_training_forward_publishes_what_the_backward_needs(B, H, W, T, sparse, c_oracle):
+    """The training form for the configuration the reference trains (CSPN_ours, K = 3, fp32): every history plane and the
+    softmax tap volume equal cspn_pac_prepare + cspn_propagate(history) bit for bit; gradients through the module (resident
+    forward, resident reverse sweep on the published volume, fused PAC tail) equal the multi-launch path's and the fp64 oracle's."""
+    from oracle import cspn_oracle as orc
+    K = 3
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=90)
+    xt, gt = dev(x)[:, 0].contiguous(), dev(gd)
+    st = dev(s)[:, 0].contiguous() if sparse else None
+    with torch.no_grad():
+        wk0, _ = F.pac_prepare(gt)
+        _, hist0 = F.propagate(wk0, xt, st, K, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True)
+        out1, hist1, wk1 = F.pac_forward_resident_history(gt, xt, st, T)
+    assert torch.equal(wk1, wk0) and torch.equal(hist1, hist0) and torch.equal(out1, hist0[T - 1])
+    if B * H * W > 3 * 228 * 304:
+        return
+    cot = c_oracle.hash_normal(91, 9, (B, 1, H, W))
+    grads = {}
+    for mode in ("on", "off"):
+        xg, gg = dev(x).requires_grad_(True), dev(gd).requires_grad_(True)
+        with resident(mode):
+            out = pkg.CSPN_ours.AffinityPropagate(T)(xg, gg, sparse_depth=dev(s))
+            out.backward(dev(cot))
+        grads[mode] = (xg.grad.cpu().numpy(), gg.grad.cpu().numpy())
+    F.ensure_resident_ok()
+    wx, wg = orc.pac_backward(x, gd, s, cot, T, np.float64)
+    for got, want, tol in ((grads["on"][0], wx, 5e-5), (grads["on"][1], wg, 5e-4)):
+        assert float(np.abs(got - want).max()) <= tol * max(1e-12, float(np.abs(want).max()))
+    assert np.allclose(grads["on"][0], grads["off"][0], rtol=0, atol=1e-6 * float(np.abs(wx).max()))
+    assert np.allclose(grads["on"][1], grads["off"][1], rtol=0, atol=1e-6 * float(np.abs(wg).max()))

@@ -20,16 +20,18 @@ ap.add_argument("--sparse", action="store_true")
 ap.add_argument("--T", type=int, default=0, help="propagation steps (default: 24 for K=3, 12 for K=5)")
 ap.add_argument("--K", type=int, default=3)
 ap.add_argument("--dtype", choices=("f32", "f16"), default="f32")
+ap.add_argument("--module", choices=("auto", "new", "ours"), default="auto", help="K = 3: CSPN_new (default) or CSPN_ours (softmax taps)")
 a = ap.parse_args()
 dev = "cuda:0"
 dt = torch.float16 if a.dtype == "f16" else torch.float32
 T = a.T or (24 if a.K == 3 else 12)
-C = 12 if a.K == 3 else a.K * a.K - 1
+ours = a.module == "ours" or (a.module == "auto" and a.K != 3)
+C = a.K * a.K - 1 if ours else 12
 g = torch.randn(a.batch, C, a.H, a.W, device=dev).to(dt).requires_grad_(True)
 d = (torch.rand(a.batch, 1, a.H, a.W, device=dev) * 10).to(dt).requires_grad_(True)
 s = (d.detach() * (torch.rand_like(d) < 0.007)) if a.sparse else None
 cot = torch.randn(a.batch, 1, a.H, a.W, device=dev).to(dt)
-if a.K == 3:
+if not ours:
     m = pkg.CSPN_new.AffinityPropagate(T, 3)
     run = lambda: m(g, d, s)                   # noqa: E731
 else:
