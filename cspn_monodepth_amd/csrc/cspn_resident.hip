@@ -109,6 +109,7 @@ __device__ __forceinline__ float ld1_dev(gptr p) {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const GLB unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+constexpr int RES_THREADS = 512;
 // The two depth buffers of the step loop sit a COMPILE-TIME distance apart (RES_PP floats; the second one starts there
 // whatever the region size): with the step loop unrolled by two, "the other buffer" is then an immediate offset of the
 // ds_read / ds_write instead of a second set of row addresses (7 VGPRs the 256-register instances do not have), and no
@@ -241,7 +242,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // ---- 1. weights of the owned quads, derived once from the raw guidance (CSPN_new.py:29-70, :124-127) -------------
     float wreg[NQ][NT][4];
     unsigned in_img = 0, interior = 0;
-    float* const md_lds = lds + RES_PP + (size_t)a.dr * a.ls;     // private slots: m * d0 of the owned quads
+    // private slots: m * d0 of the owned quads, NQ consecutive 16-byte slots per THREAD — quad i is base + an immediate offset, so
+    // the step loop carries no address arithmetic for them (indexed by region row and column they cost the blended training
+    // instances 6-7 scratch reloads per step: +25 us per launch); stride NQ * 16 bytes is bank-conflict free for NQ = 1, 3, 5
+    float* const md_lds = lds + RES_PP + (size_t)a.dr * a.ls;
     const float* __restrict__ gq = uniform_ptr(a.g + (size_t)b * a.g_bs);
     // tap j = (dy,dx) row-major without the centre reads channel 7-j at p+off_j: the aligned quad of row y+dy gives three of
     // the four shifted values, the fourth is the neighbouring lane's quad (DPP) or, at strip ends / wave edges, a scalar.
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             const float4 m = make_float4(ok ? sgnf(mraw[i].x) : 0.f, ok ? sgnf(mraw[i].y) : 0.f, ok ? sgnf(mraw[i].z) : 0.f, ok ? sgnf(mraw[i].w) : 0.f);
             const float omq[4] = {1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w};
             if (TRANS) {                               // PREMASK: the private plane holds 1-m, applied to every step's result
-                *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) = make_float4(omq[0], omq[1], omq[2], omq[3]);
+                *reinterpret_cast<float4*>(md_lds + (tid * NQ + i) * 4) = make_float4(omq[0], omq[1], omq[2], omq[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                     for (int e = 0; e < 4; ++e) wreg[i][j][e] *= omq[e];
                 // the private slot receives m now and becomes m * d0 once the depth region is staged (the owned quads of
                 // d0 are read from LDS there anyway: no second global load, no exposed round trip)
-                *reinterpret_cast<float4*>(md_lds + (r * wq + sx) * 4) = m;
+                *reinterpret_cast<float4*>(md_lds + (tid * NQ + i) * 4) = m;
             }
         }
     }
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 if (r0L + i < wr) {
-                    float4* slot = reinterpret_cast<float4*>(md_lds + ((r0L + i) * wq + sxL) * 4);
+                    float4* slot = reinterpret_cast<float4*>(md_lds + (tid * NQ + i) * 4);
                     const float4 m = *slot;
                     // plain products, as the reference's  m * d0  (0 * inf = nan spreads like there); quads outside the
                     // image hold m = 0 and a zero-padded d0
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                             }
                         float keep[4];                 // the state carried to the next step
                         if (BLEND) {
-                            const float4 m4 = *reinterpret_cast<const float4*>(md_lds + (min(r0L + i, wr - 1) * wq + sxL) * 4);
+                            const float4 m4 = *reinterpret_cast<const float4*>(md_lds + (tid * NQ + i) * 4);
                             if (TRANS) {
                                 keep[0] = m4.x * u[0]; keep[1] = m4.y * u[1]; keep[2] = m4.z * u[2]; keep[3] = m4.w * u[3];
                             } else {
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 }
             }
         }
-        float* part = lds + RES_PP + (size_t)a.dr * a.ls + (size_t)(BLEND ? 1 : 0) * a.wr * 4 * a.wq;
+        float* part = lds + RES_PP + (size_t)a.dr * a.ls + (size_t)(BLEND ? 1 : 0) * NTHREADS * NQ * 4;
         const int wave = tid >> 6;
         __syncthreads();
 #pragma unroll
@@ -740,7 +744,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-constexpr int RES_THREADS = 512;
 constexpr int RES_MAX_NQ = 5;
 
 struct ResGeom {
@@ -764,8 +767,8 @@ int cu_count() {
 
 // LDS of one workgroup: buffer 0 in the first RES_PP floats, buffer 1 behind it, then the private m * d0 quads (sparse
 // blend) and the 10 x 16 partial sums of the fused metrics.
-size_t res_lds_bytes(int dr, int ls, int wr, int wq, int blend) {
-    return ((size_t)RES_PP + (size_t)dr * ls + (size_t)(blend ? 1 : 0) * wr * 4 * wq + 16 * 10) * sizeof(float);
+size_t res_lds_bytes(int dr, int ls, int nq, int blend) {
+    return ((size_t)RES_PP + (size_t)dr * ls + (size_t)(blend ? 1 : 0) * RES_THREADS * nq * 4 + 16 * 10) * sizeof(float);
 }
 
 // Mirror of the kernel's region placement: does every region of every tile lie inside the (valid part of the) image?
@@ -819,7 +822,7 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
                 if (nq > RES_MAX_NQ) continue;
                 const int dr = wr + 2, ls = 4 * wq + 8;
                 if ((size_t)dr * ls > (size_t)RES_PP) continue;                      // one depth buffer per RES_PP slot
-                const size_t ldsb = res_lds_bytes(dr, ls, wr, wq, blend);
+                const size_t ldsb = res_lds_bytes(dr, ls, nq, blend);
                 if (ldsb > 160 * 1024) continue;
                 int ipl = ncu / tiles;
                 if (ipl > B) ipl = B;
@@ -982,7 +985,7 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         g.wq = (g.tw + 2 * g.hxw) / 4; g.wr = g.th + 2 * g.hyw;
         g.dr = g.wr + 2; g.ls = 4 * g.wq + 8;
         g.nq = g.wq > 0 && g.wq <= RES_THREADS ? ceil_div(g.wr, RES_THREADS / g.wq) : RES_MAX_NQ + 1;
-        g.lds_bytes = res_lds_bytes(g.dr, g.ls, g.wr, g.wq, blend);
+        g.lds_bytes = res_lds_bytes(g.dr, g.ls, g.nq, blend);
         g.imgs_per_launch = rp.images_per_launch;
         const int phases = ceil_div(T, Se);
         if ((g.tw & 3) || g.nq > RES_MAX_NQ || g.lds_bytes > 160 * 1024 || (size_t)g.dr * g.ls > (size_t)RES_PP || (phases > 1 && (Se & 1)) || g.tiles_x * g.tw < W || g.tiles_y * g.th < H ||
