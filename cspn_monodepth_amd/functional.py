@@ -670,7 +670,11 @@ class _ResidentCheckpoint(object):
         if self.seq is not None:
             words = st["host_err_np"]
             t_end = None
+            spins = 0
             while True:
+                spins += 1
+                if spins % 4096 == 0:
+                    time.sleep(0)                       # long waits (a stalled device) yield the interpreter to other threads
                 if words[0] != 0:
                     break
                 if ((int(words[1]) - self.seq) & 0xffffffff) < 0x80000000:      # done word has reached (or passed) this call
