@@ -272,6 +272,8 @@ def run_train(args, wl, world, rank, local_rank, device):
     torch.backends.cudnn.benchmark = (args.conv_autotune == "on")
     torch.manual_seed(0)
     model = unet_cspn_nyu.resnet50(reference_state_dict=False, cspn_plan=parse_plan(args.plan)).to(device)
+    if args.memory_format == "channels_last":      # stock-op layout choice only: the HIP ops take their planes contiguous
+        model = model.to(memory_format=torch.channels_last)
     if world > 1:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
         ddp = nn.parallel.DistributedDataParallel(model, device_ids=[device.index] if args.backend == "nccl" else None,
@@ -284,6 +286,8 @@ def run_train(args, wl, world, rank, local_rank, device):
     rgb = torch.rand(B, 3, H, W, device=device, generator=gen)
     sparse = depth * (torch.rand(B, 1, H, W, device=device, generator=gen) < 500.0 / (H * W))
     x = torch.cat([rgb, sparse], 1)
+    if args.memory_format == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
     target = torch.where(torch.rand(B, 1, H, W, device=device, generator=gen) < 0.05, torch.zeros_like(depth), depth)
 
     cspn = model.post_process_layer
@@ -346,7 +350,7 @@ def run_train(args, wl, world, rank, local_rank, device):
                "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
                           "prop_time": wl["T"], "optimizer": "SGD(momentum 0.9, wd 1e-4)", "loss": "MaskedL1",
                           "parameters": int(sum(p.numel() for p in model.parameters())),
-                          "conv_autotune": args.conv_autotune,
+                          "conv_autotune": args.conv_autotune, "memory_format": args.memory_format,
                           "parallelism": "DDP x%d over RCCL + SyncBatchNorm" % world if world > 1 else "single GPU"},
                "roofline": None,
                "cspn_module": {"forward_us_p50": med(fwd_us), "backward_us_p50": med(bwd_us),
@@ -369,6 +373,8 @@ def main():
     ap.add_argument("--workload", default="nyu", choices=sorted(WORKLOADS))
     ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
     ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
+    ap.add_argument("--memory-format", default="contiguous", choices=("contiguous", "channels_last"),
+                    help="--workload train: memory format of the stock convolution stack (NCHW as the reference, or NHWC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size (experiments)")
     ap.add_argument("--graph", choices=("on", "off"), default="off",
