@@ -24,6 +24,10 @@ std::atomic<int>& force_generic_flag() {
     return flag;
 }
 
+// workgroups the any-geometry launches aim for (channel chunks / tap groups are split until there are that many): measured on
+// the C = 32 dilated row — 512 / 1024 / 2048 workgroups: forward 57 / 47 / 54 us; dL/dkernel with 1 / 2 tap groups: 58 / 88 us
+constexpr size_t ANY_WANT_WGS = 1024, ANY_WANT_WGS_GK = 256;
+
 struct ConvArgs {
     int B, C, CK, H, W, Ho, Wo, WQ;      // WQ = ceil(Wo / 4) output quads per row
     int kh, kw, sh, sw, ph, pw, dh, dw;
@@ -454,6 +458,41 @@ __global__ __launch_bounds__(256, (HOIST ? 1 : 4)) void pac_conv2d_tiled_h8(cons
     }
 }
 
+// Staging of a [nc][RH * RW] patch for the any-geometry kernels: patch element idx = threadIdx.x + 256 n -> (ry, rx),
+// advanced incrementally (integer divisions by the runtime patch width per element had made the forward VALU-bound: 6.6 k
+// VALU instructions per wavefront).  Four elements x nc channels are REQUESTED before the first is written to LDS: with one
+// element per trip a wavefront had nc loads in flight, ~19 KB per CU at the occupancy of these kernels — 3 TB/s whatever
+// the rest of the kernel did.  Raw bits under the mask, converted at the LDS write (see ld1_raw_or0).
+template <typename T>
+__device__ __forceinline__ void stage_patch_any(float* __restrict__ patch, const T* __restrict__ src, size_t splane, int nc,
+                                                int psz, int RW, int gy0, int gx0, int src_h, int src_w, int t_ry, int t_rx,
+                                                int step_ry, int step_rx) {
+    constexpr int U = 4;
+    int ry = t_ry, rx = t_rx;
+    for (int idx0 = threadIdx.x; idx0 < psz; idx0 += 256 * U) {
+        unsigned v[U][CC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int yi = gy0 + ry, xi = gx0 + rx;
+            const bool ok = idx0 + 256 * u < psz && (unsigned)yi < (unsigned)src_h && (unsigned)xi < (unsigned)src_w;
+            const size_t goff = (size_t)(ok ? yi : 0) * src_w + (ok ? xi : 0);
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) v[u][cc] = (cc < nc) ? ld1_raw_or0(src + cc * splane, goff, ok) : 0u;
+            rx += step_rx; ry += step_ry;
+            if (rx >= RW) { rx -= RW; ++ry; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = idx0 + 256 * u;
+            if (idx < psz) {
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc)
+                    if (cc < nc) patch[cc * psz + idx] = raw_to_float<T>(v[u][cc]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward, tiled, any geometry
 // Strided / dilated / non-square windows: same 64 x 16 output tile, the input patch it touches —
 // ((64-1) sw + (kw-1) dw + 1) x ((16-1) sh + (kh-1) dh + 1) — staged in dynamic LDS for `cb` channels at a time and the
@@ -461,7 +500,11 @@ __global__ __launch_bounds__(256, (HOIST ? 1 : 4)) void pac_conv2d_tiled_h8(cons
 // rows (t / 64) + 4 e: a wavefront reads 64 consecutive patch columns (stride sw), which is bank-conflict free for
 // sw = 1 — the quad-per-thread mapping of the other kernels puts 64 lanes on 8 banks here (measured 2.4x slower).
 // The price is 4-byte kernel loads and output stores (coalesced: one 256-byte row segment per wavefront).
-template <typename T, bool SHARED>
+// TRANSPOSED (unit stride only) is dL/dinput as a gather: the tile lies on the INPUT plane, the patch holds grad_out, tap
+// (i, j) of input pixel q looks at the output pixel p = q + pad - (i, j) * dilation — the patch is read at the flipped tap
+// position and the kernel value is fetched where p lives (one coalesced, shifted row segment per wavefront and tap).
+// HOIST (shared kernel of <= 9 taps): the tile's kernel values are loaded once and stay in registers across all channel batches.
+template <typename T, bool SHARED, bool TRANSPOSED, bool HOIST>
 __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restrict__ in, const T* __restrict__ kern,
                                                                 T* __restrict__ out, ConvArgs a, int tiles_x, int RW,
                                                                 int RH, int cb) {
@@ -473,9 +516,129 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restr
     const int x = tx0 + lx;
     const int b = blockIdx.z;
     const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
-    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const int src_h = TRANSPOSED ? a.Ho : a.H, src_w = TRANSPOSED ? a.Wo : a.W;     // the plane the patch is cut from
+    const int dst_h = TRANSPOSED ? a.H : a.Ho, dst_w = TRANSPOSED ? a.W : a.Wo;     // the plane the tile lies on
+    const size_t kplane = (size_t)a.Ho * a.Wo, splane = (size_t)src_h * src_w, dplane = (size_t)dst_h * dst_w;
     const int psz = RH * RW, ntap = a.kh * a.kw;
-    const int gy0 = ty0 * a.sh - a.ph, gx0 = tx0 * a.sw - a.pw;          // input coordinates of patch element (0,0)
+    // source coordinates of patch element (0,0)
+    const int gy0 = TRANSPOSED ? ty0 + a.ph - (a.kh - 1) * a.dh : ty0 * a.sh - a.ph;
+    const int gx0 = TRANSPOSED ? tx0 + a.pw - (a.kw - 1) * a.dw : tx0 * a.sw - a.pw;
+    bool live[4];
+    size_t opix[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int y = ty0 + ly0 + 4 * e;
+        live[e] = x < dst_w && y < dst_h;
+        opix[e] = (size_t)(live[e] ? y : 0) * dst_w + (live[e] ? x : 0);
+    }
+    const int step_ry = 256 / RW, step_rx = 256 - step_ry * RW;         // uniform: one division per workgroup
+    const int t_ry = threadIdx.x / RW, t_rx = threadIdx.x - t_ry * RW;   // one division per thread
+    const int base0 = TRANSPOSED ? ly0 * RW + lx : ly0 * a.sh * RW + lx * a.sw;
+    const int estep = TRANSPOSED ? 4 * RW : 4 * a.sh * RW;
+    // kernel value of tap (ti, tj) for the thread's four pixels: at the output pixel itself, or (transposed) at the output
+    // pixel p that reads input pixel q through this tap — where there is no such p the value is 0 and so is the patch
+    // element it multiplies (p lies outside grad_out)
+    auto load_taps = [&](const T* kp, int ti, int tj, float (&kv)[4]) {
+        if constexpr (TRANSPOSED) {
+            const int kx = x + a.pw - tj * a.dw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ky = ty0 + ly0 + 4 * e + a.ph - ti * a.dh;
+                const bool ok = live[e] && (unsigned)ky < (unsigned)a.Ho && (unsigned)kx < (unsigned)a.Wo;
+                kv[e] = ld1_or0(kp, ok ? (size_t)ky * a.Wo + kx : (size_t)0, ok);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, opix[e], live[e]);
+        }
+    };
+    constexpr int NH = 9;
+    float kh_[HOIST ? NH : 1][4];
+    if constexpr (HOIST) {
+        int ti = 0, tj = 0;
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+            if (k < ntap) {
+                load_taps(kern + ((size_t)b * ntap + k) * kplane, ti, tj, kh_[k]);
+                if (++tj == a.kw) { tj = 0; ++ti; }
+            }
+        }
+    }
+    for (int c = c_begin; c < c_end; c += cb) {
+        const int nc = min(cb, c_end - c);
+        __syncthreads();
+        stage_patch_any<T>(patch, in + ((size_t)b * a.C + c) * splane, splane, nc, psz, RW, gy0, gx0, src_h, src_w, t_ry, t_rx,
+                           step_ry, step_rx);
+        __syncthreads();
+        float acc[CC][4];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
+        int ti = 0, tj = 0;
+        auto one_tap = [&](int tap, const float (*hoisted)[4]) {
+            const int base = TRANSPOSED ? base0 + (a.kh - 1 - ti) * a.dh * RW + (a.kw - 1 - tj) * a.dw
+                                        : base0 + ti * a.dh * RW + tj * a.dw;
+            float kv[4];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kv[e] = (*hoisted)[e];
+            } else if constexpr (SHARED) {
+                load_taps(kern + ((size_t)b * ntap + tap) * kplane, ti, tj, kv);
+            }
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                if (cc < nc) {
+                    if constexpr (!SHARED) load_taps(kern + (((size_t)b * a.C + c + cc) * ntap + tap) * kplane, ti, tj, kv);
+                    const float* pp = patch + cc * psz + base;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(kv[e], pp[e * estep], acc[cc][e]);
+                }
+            }
+            if (++tj == a.kw) { tj = 0; ++ti; }
+        };
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int k = 0; k < NH; ++k)
+                if (k < ntap) one_tap(k, &kh_[k]);
+        } else {
+#pragma unroll 2
+            for (int tap = 0; tap < ntap; ++tap) one_tap(tap, nullptr);
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (cc < nc) {
+                T* op = out + ((size_t)b * a.C + c + cc) * dplane;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (live[e]) st1(op + opix[e], acc[cc][e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dkernel, tiled, any geometry
+// The input patch of a 64 x 16 output tile staged as in pac_conv2d_fwd_tiled_any; every thread turns the grad_out values of
+// its four pixels into the kernel gradients of `tpg` taps.  A shared kernel sums over ALL channels in registers (NTM taps at
+// most per workgroup: blockIdx.y = tap group) and writes once; a per-channel kernel is an outer product (blockIdx.y =
+// channel chunk, every tap written as it is formed).
+template <typename T, bool SHARED, int NTM>
+__global__ __launch_bounds__(256) void pac_conv2d_gk_any(const T* __restrict__ gout, const T* __restrict__ in,
+                                                         T* __restrict__ gk, ConvArgs a, int tiles_x, int RW, int RH,
+                                                         int cb, int tpg) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];       // [cb][RH * RW]
+    const int tid = blockIdx.x;
+    const int ty = tid / tiles_x, tx = tid - ty * tiles_x;
+    const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    const int x = tx0 + lx;
+    const int b = blockIdx.z;
+    const int ntap = a.kh * a.kw;
+    const int c_begin = SHARED ? 0 : blockIdx.y * a.cchunk, c_end = SHARED ? a.C : min(a.C, c_begin + a.cchunk);
+    const int t_begin = SHARED ? blockIdx.y * tpg : 0, t_end = SHARED ? min(ntap, t_begin + tpg) : ntap;
+    const size_t oplane = (size_t)a.Ho * a.Wo, iplane = (size_t)a.H * a.W;
+    const int psz = RH * RW;
+    const int gy0 = ty0 * a.sh - a.ph, gx0 = tx0 * a.sw - a.pw;
     bool live[4];
     size_t opix[4];
 #pragma unroll
@@ -484,64 +647,66 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restr
         live[e] = x < a.Wo && y < a.Ho;
         opix[e] = (size_t)(live[e] ? y : 0) * a.Wo + (live[e] ? x : 0);
     }
-    const int step_ry = 256 / RW, step_rx = 256 - step_ry * RW;         // uniform: one division per workgroup
-    const int t_ry = threadIdx.x / RW, t_rx = threadIdx.x - t_ry * RW;   // one division per thread
+    const int step_ry = 256 / RW, step_rx = 256 - step_ry * RW;
+    const int t_ry = threadIdx.x / RW, t_rx = threadIdx.x - t_ry * RW;
+    const int base0 = ly0 * a.sh * RW + lx * a.sw, estep = 4 * a.sh * RW;
+    const int ti0 = t_begin / a.kw, tj0 = t_begin - ti0 * a.kw;
+    float acc[SHARED ? NTM : 1][4];
+#pragma unroll
+    for (int k = 0; k < (SHARED ? NTM : 1); ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
     for (int c = c_begin; c < c_end; c += cb) {
         const int nc = min(cb, c_end - c);
         __syncthreads();
-        // patch element idx = threadIdx.x + 256 n -> (ry, rx), advanced incrementally: integer divisions by the runtime
-        // patch width per element made this kernel VALU-bound (6.6 k VALU instructions per wavefront)
-        {
-            int ry = t_ry, rx = t_rx;
-            for (int idx = threadIdx.x; idx < psz; idx += 256) {
-                const int yi = gy0 + ry, xi = gx0 + rx;
-                const bool ok = (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
-                const size_t goff = (size_t)(ok ? yi : 0) * a.W + (ok ? xi : 0);
-                for (int cc = 0; cc < nc; ++cc)
-                    patch[cc * psz + idx] = ld1_or0(in + ((size_t)b * a.C + c + cc) * iplane, goff, ok);
-                rx += step_rx; ry += step_ry;
-                if (rx >= RW) { rx -= RW; ++ry; }
-            }
-        }
-        __syncthreads();
-        float acc[CC][4];
+        // the batch's grad_out values are requested first: they travel while the patch is staged
+        unsigned graw[CC][4];
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
-        const int base0 = ly0 * a.sh * RW + lx * a.sw, estep = 4 * a.sh * RW;
-        int ti = 0, tj = 0;
-#pragma unroll 2
-        for (int tap = 0; tap < ntap; ++tap) {
-            const int base = base0 + ti * a.dh * RW + tj * a.dw;
-            if (++tj == a.kw) { tj = 0; ++ti; }
-            float kv[4];
+            for (int e = 0; e < 4; ++e)
+                graw[cc][e] = ld1_raw_or0(gout + ((size_t)b * a.C + c + (cc < nc ? cc : 0)) * oplane, opix[e], live[e] && cc < nc);
+        stage_patch_any<T>(patch, in + ((size_t)b * a.C + c) * iplane, iplane, nc, psz, RW, gy0, gx0, a.H, a.W, t_ry, t_rx,
+                           step_ry, step_rx);
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (cc >= nc) continue;
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = raw_to_float<T>(graw[cc][e]);
+            const float* pc = patch + cc * psz + base0;
+            int ti = ti0, tj = tj0;
             if constexpr (SHARED) {
-                const T* kp = kern + ((size_t)b * ntap + tap) * oplane;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, opix[e], live[e]);
-            }
+                for (int k = 0; k < NTM; ++k) {
+                    if (t_begin + k < t_end) {
+                        const float* pp = pc + ti * a.dh * RW + tj * a.dw;
 #pragma unroll
-            for (int cc = 0; cc < CC; ++cc) {
-                if (cc < nc) {
-                    if constexpr (!SHARED) {
-                        const T* kp = kern + (((size_t)b * a.C + c + cc) * ntap + tap) * oplane;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) kv[e] = ld1_or0(kp, opix[e], live[e]);
+                        for (int e = 0; e < 4; ++e) acc[k][e] += g[e] * pp[e * estep];
+                        if (++tj == a.kw) { tj = 0; ++ti; }
                     }
-                    const float* pp = patch + cc * psz + base;
+                }
+            } else {
+                T* dst = gk + ((size_t)b * a.C + c + cc) * ntap * oplane;
+                for (int tap = 0; tap < ntap; ++tap) {
+                    const float* pp = pc + ti * a.dh * RW + tj * a.dw;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(kv[e], pp[e * estep], acc[cc][e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (live[e]) st1(dst + (size_t)tap * oplane + opix[e], g[e] * pp[e * estep]);
+                    if (++tj == a.kw) { tj = 0; ++ti; }
                 }
             }
         }
+    }
+    if constexpr (SHARED) {
 #pragma unroll
-        for (int cc = 0; cc < CC; ++cc) {
-            if (cc < nc) {
-                T* op = out + ((size_t)b * a.C + c + cc) * oplane;
+        for (int k = 0; k < NTM; ++k) {
+            if (t_begin + k < t_end) {
+                T* dst = gk + ((size_t)b * ntap + t_begin + k) * oplane;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (live[e]) st1(op + opix[e], acc[cc][e]);
+                    if (live[e]) st1(dst + opix[e], acc[k][e]);
             }
         }
     }
@@ -1077,7 +1242,7 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
     t.tiles_x = ceil_div(t.dst_w, TILE_W);
     const int tiles = t.tiles_x * ceil_div(t.dst_h, TILE_H);
     // every channel chunk re-reads the kernel planes, so only split as far as filling the chip needs (~4 x 256 groups)
-    const size_t want = 1024, have = (size_t)tiles * a.B;
+    const size_t want = ANY_WANT_WGS, have = (size_t)tiles * a.B;
     int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)a.C);
     if (a.CK != 1) nchunk = (int)std::min<size_t>((4 * want + have - 1) / have, (size_t)a.C);   // nothing is re-read
     t.cchunk = ceil_div(a.C, std::max(nchunk, 1));
@@ -1114,10 +1279,11 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
     const T* k = static_cast<const T*>(kern);
     T* o = static_cast<T*>(out);
     const bool shared = a.CK == 1;
-    if (!a.force_scalar && a.sh == 1 && a.sw == 1 && (size_t)a.H * a.W < ((size_t)1 << 31)) {
-        // other unit-stride geometries (dilation, non-square or even windows): LDS-tiled when the input patch of a 64 x 16
-        // output tile fits 64 KiB for at least one channel.  Strided windows stay on the scalar kernel: their patches are
-        // stride^2 larger per output and the tiled form measured slower (87 vs 77 us at stride 2).
+    if (!a.force_scalar && (size_t)a.H * a.W < ((size_t)1 << 31)) {
+        // every other geometry (stride, dilation, non-square or even windows): LDS-tiled when the input patch of a 64 x 16
+        // output tile fits 64 KiB for at least one channel.  (Strided windows used to stay on the scalar kernel — their
+        // patches are stride^2 larger per output and the tiled form measured 87 vs 77 us at stride 2; that was the old
+        // staging loop, four loads in flight per wavefront: with stage_patch_any it is 42 vs 76 us.)
         const long RWl = ((long)(TILE_W - 1) * a.sw + (long)(a.kw - 1) * a.dw + 1 + 3) & ~3L;
         const long RHl = (long)(TILE_H - 1) * a.sh + (long)(a.kh - 1) * a.dh + 1;
         const long psz = RWl * RHl;
@@ -1125,13 +1291,14 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
         cb = std::min(cb, a.C);
         if (cb >= 1) {
             const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
-            const size_t want = 1024, have = (size_t)tiles * a.B;
+            const size_t want = ANY_WANT_WGS, have = (size_t)tiles * a.B;
             int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, cb));
             a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
             const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
             const size_t lds = (size_t)cb * psz * sizeof(float);
-            if (shared) pac_conv2d_fwd_tiled_any<T, true><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
-            else pac_conv2d_fwd_tiled_any<T, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            if (shared && a.kh * a.kw <= 9) pac_conv2d_fwd_tiled_any<T, true, false, true><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else if (shared) pac_conv2d_fwd_tiled_any<T, true, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else pac_conv2d_fwd_tiled_any<T, false, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
             HIP_OK(hipGetLastError());
             return 1;
         }
@@ -1210,6 +1377,41 @@ int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStr
         return a.kh == 3 ? conv_gk_tiled<T, 3>(g, i, o, a, st)
              : a.kh == 5 ? conv_gk_tiled<T, 5>(g, i, o, a, st) : conv_gk_tiled<T, 7>(g, i, o, a, st);
     }
+    if (!a.force_scalar && a.sh == 1 && a.sw == 1 && (size_t)a.H * a.W < ((size_t)1 << 31) &&
+        (size_t)a.Ho * a.Wo < ((size_t)1 << 31)) {
+        // other unit-stride windows: input patch in LDS, all taps (per-channel kernel) or a group of <= 9 taps (shared kernel:
+        // the sum over channels stays in registers) per workgroup.  (The kernel takes strides too, but a strided window's
+        // patch is stride^2 larger per output: 85 vs 70 us for the scalar kernel at stride 2.)
+        constexpr int NTM = 9;
+        const long RWl = ((long)(TILE_W - 1) * a.sw + (long)(a.kw - 1) * a.dw + 1 + 3) & ~3L;
+        const long RHl = (long)(TILE_H - 1) * a.sh + (long)(a.kh - 1) * a.dh + 1;
+        const long psz = RWl * RHl;
+        int cb = (int)std::min<long>(CC, (64 * 1024 / 4) / std::max(psz, 1L));
+        cb = std::min(cb, a.C);
+        if (cb >= 1) {
+            const int tiles_x = ceil_div(a.Wo, TILE_W), tiles = tiles_x * ceil_div(a.Ho, TILE_H);
+            const int ntap = a.kh * a.kw;
+            const size_t have = (size_t)tiles * a.B;
+            const size_t lds = (size_t)cb * psz * sizeof(float);
+            const T* g = static_cast<const T*>(gout);
+            const T* i = static_cast<const T*>(in);
+            T* o = static_cast<T*>(gk);
+            if (a.CK == 1) {
+                // enough workgroups to fill the chip: split the taps into more groups when there are few tiles
+                const int want_groups = (int)std::min<size_t>((size_t)ntap, (ANY_WANT_WGS_GK + have - 1) / have);
+                const int tpg = std::max(1, std::min(NTM, ceil_div(ntap, std::max(want_groups, 1))));
+                const dim3 grid(tiles, ceil_div(ntap, tpg), a.B), block(256);
+                pac_conv2d_gk_any<T, true, NTM><<<grid, block, lds, st>>>(g, i, o, a, tiles_x, (int)RWl, (int)RHl, cb, tpg);
+            } else {
+                int nchunk = (int)std::min<size_t>((1024 + have - 1) / have, (size_t)ceil_div(a.C, cb));
+                a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
+                const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
+                pac_conv2d_gk_any<T, false, NTM><<<grid, block, lds, st>>>(g, i, o, a, tiles_x, (int)RWl, (int)RHl, cb, 0);
+            }
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     const dim3 grid(ceil_div(a.Ho * a.WQ, 256), a.kh * a.kw, a.B), block(256);
     const T* g = static_cast<const T*>(gout);
     const T* i = static_cast<const T*>(in);
@@ -1228,6 +1430,32 @@ int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int
     if (tiled_geometry(a) && !a.force_scalar && (size_t)a.Ho * a.Wo < ((size_t)1 << 31))
         return launch_tiled_k<T, true>(static_cast<const T*>(gout), static_cast<const T*>(kern), static_cast<T*>(gin), a,
                                        in_vec, st);
+    if (!a.force_scalar && a.sh == 1 && a.sw == 1 && (size_t)a.H * a.W < ((size_t)1 << 31) &&
+        (size_t)a.Ho * a.Wo < ((size_t)1 << 31)) {
+        // other unit-stride windows (dilated, non-square, even): the any-geometry tiled kernel, transposed — the tile lies
+        // on the input plane, the grad_out patch it gathers from has the extents of the forward's input patch
+        const long RWl = ((long)(TILE_W - 1) + (long)(a.kw - 1) * a.dw + 1 + 3) & ~3L;
+        const long RHl = (long)(TILE_H - 1) + (long)(a.kh - 1) * a.dh + 1;
+        const long psz = RWl * RHl;
+        int cb = (int)std::min<long>(CC, (64 * 1024 / 4) / std::max(psz, 1L));
+        cb = std::min(cb, a.C);
+        if (cb >= 1) {
+            const int tiles_x = ceil_div(a.W, TILE_W), tiles = tiles_x * ceil_div(a.H, TILE_H);
+            const size_t want = ANY_WANT_WGS, have = (size_t)tiles * a.B;
+            int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, cb));
+            a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
+            const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
+            const size_t lds = (size_t)cb * psz * sizeof(float);
+            const T* g = static_cast<const T*>(gout);
+            const T* k = static_cast<const T*>(kern);
+            T* o = static_cast<T*>(gin);
+            if (a.CK == 1 && a.kh * a.kw <= 9) pac_conv2d_fwd_tiled_any<T, true, true, true><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else if (a.CK == 1) pac_conv2d_fwd_tiled_any<T, true, true, false><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else pac_conv2d_fwd_tiled_any<T, false, true, false><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     const int in_wq = ceil_div(a.W, 4);
     const int gx = ceil_div(a.H * in_wq, 256);
     a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);

@@ -165,10 +165,12 @@ def test_fuzz_tiled_geometry_both_kernels(seed):
         assert nmax(gk, wgk) <= tol, (tag, scalar)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(36))
 def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed):
-    """Unit stride with dilation / non-square / even windows takes the any-geometry LDS-tiled forward; compare it and the
-    scalar kernel (cspn_pac_force_generic) with the oracle on multi-tile frames."""
+    """Unit stride with dilation / non-square / even windows takes the any-geometry LDS-tiled kernels — forward, dL/dinput
+    (the same kernel transposed) and dL/dkernel (tap groups of a shared kernel summed over channels in registers, outer
+    product for a per-channel kernel); compare them and the scalar kernels (cspn_pac_force_generic) with the oracle on
+    multi-tile frames, ragged edges, more channels than one LDS batch, fp16 now and then."""
     rng = np.random.default_rng(3000 + seed)
     k = (int(rng.integers(1, 6)), int(rng.integers(1, 6)))
     d = (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
@@ -179,14 +181,42 @@ def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed):
     W = int(rng.integers(max(1, d[1] * (k[1] - 1) + 1 - 2 * p[1]), 180))
     B, C = int(rng.integers(1, 3)), int(rng.integers(1, 10))
     CK = C if seed % 2 else 1
+    dt = torch.float16 if seed % 6 == 4 else torch.float32
+    Ho, Wo = porc.out_size((H, W), k, 1, p, d)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kern = (rng.standard_normal((B, CK, k[0], k[1], Ho, Wo)) * (0.3 if dt == torch.float16 else 1.0)).astype(np.float32)
+    cot = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    if dt == torch.float16:
+        x, kern, cot = (v.astype(np.float16).astype(np.float32) for v in (x, kern, cot))
+    want = porc.pac_conv2d_forward(x, kern, k, 1, p, d, dtype=np.float64)
+    wgi, wgk = porc.pac_conv2d_backward(x, kern, cot, k, 1, p, d)
+    tol = 2e-3 if dt == torch.float16 else TOL
+    for scalar in (0, 1):
+        tag = (B, C, CK, H, W, k, p, d, str(dt), scalar)
+        with force_generic(scalar):
+            out, gi, gk = run_all(x, kern, cot, k, 1, p, d, dt)
+        assert nmax(out, want) <= tol, tag
+        assert nmax(gi, wgi) <= tol, tag
+        assert nmax(gk, wgk) <= tol, tag
+
+
+@pytest.mark.parametrize("C,CK,k,p,d", [(32, 1, (3, 3), (2, 2), (2, 2)), (6, 6, (3, 3), (2, 2), (2, 2)), (5, 1, (5, 5), (4, 4), (2, 2)),
+                                         (3, 1, (2, 4), (1, 3), (3, 2)), (4, 4, (4, 1), (0, 0), (1, 1))])
+def test_dilated_windows_full_frame_tiled_equals_generic(C, CK, k, p, d):
+    """At frame size (228 x 304: 5 x 15 tiles, every tap-group split of a shared kernel) the tiled any-geometry kernels
+    against the scalar ones."""
+    rng = np.random.default_rng(77)
+    B, H, W = 2, 228, 304
     Ho, Wo = porc.out_size((H, W), k, 1, p, d)
     x = rng.standard_normal((B, C, H, W)).astype(np.float32)
     kern = rng.standard_normal((B, CK, k[0], k[1], Ho, Wo)).astype(np.float32)
-    want = porc.pac_conv2d_forward(x, kern, k, 1, p, d, dtype=np.float64)
-    for scalar in (0, 1):
-        with force_generic(scalar), torch.no_grad():
-            out = pac.conv2d(dev(x), dev(kern), k, 1, p, d).cpu().numpy()
-        assert nmax(out, want) <= TOL, (B, C, CK, H, W, k, p, d, scalar)
+    cot = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    with force_generic(0):
+        got = run_all(x, kern, cot, k, 1, p, d)
+    with force_generic(1):
+        ref = run_all(x, kern, cot, k, 1, p, d)
+    for g_, r_, what in zip(got, ref, ("out", "grad_input", "grad_kernel")):
+        assert nmax(g_, r_) <= 2e-6, (what, C, CK, k, p, d)
 
 
 def test_padding_zero_times_nonfinite_kernel_is_nan_like_unfold():

@@ -16,7 +16,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cspn_monodepth_amd.base import pac            # noqa: E402
-from tools.tune import timed                       # noqa: E402
+from tools.tune import timed as _timed_once        # noqa: E402
+
+
+def timed(fn, reps):
+    """Best of three batches: one allocator event (a cached block split or returned between cases) inside a batch of 20
+    otherwise shows up as milliseconds on a 15 us kernel."""
+    return min(_timed_once(fn, reps) for _ in range(3))
 
 PEAK = 8000.0
 CASES = [   # name, B, C, CK, H, W, K, stride, pad, dil, dtype
@@ -41,10 +47,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default="")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring filter on the case names (skips the un-pooling rows)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rows = []
     for name, B, C, CK, H, W, K, s, p, d, dt in CASES:
+        if args.only and args.only not in name:
+            continue
         Ho, Wo = pac.output_size((H, W), K, s, p, d)
         x = torch.randn(B, C, H, W, device=dev, dtype=dt)
         k = torch.randn(B, CK, K, K, Ho, Wo, device=dev, dtype=dt)
@@ -68,7 +77,7 @@ def main():
             name, t_f, row["fwd_GBs"], 100 * row["fwd_frac"], t_b, row["bwd_GBs"], 100 * row["bwd_frac"], t_gi, t_gk, t_u, t_u / t_f), flush=True)
     # zero-insertion un-pooling at the five decoder stages of unet_cspn_nyu (B = 24)
     from cspn_monodepth_amd.network import up_pooling as up
-    for (H, W, oh, ow, C) in ((8, 10, 15, 19, 1024), (15, 19, 29, 38, 512), (29, 38, 57, 76, 256), (57, 76, 114, 152, 128),
+    for (H, W, oh, ow, C) in () if args.only else ((8, 10, 15, 19, 1024), (15, 19, 29, 38, 512), (29, 38, 57, 76, 256), (57, 76, 114, 152, 128),
                               (114, 152, 228, 304, 64)):
         x = torch.randn(24, C, H, W, device=dev)
         g = torch.randn(24, C, oh, ow, device=dev)
