@@ -185,7 +185,7 @@ struct TiledArgs {
 };
 
 template <typename T, int K, bool HOIST, int CB, bool TRANSPOSED>
-__global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
+__global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
                                                                          T* __restrict__ dst, TiledArgs a) {
     constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);     // LDS row pitch, a multiple of 4
     constexpr int RH = TILE_H + K - 1;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T
     };
     float kr[KR][4];
     // taps [first, first+n) in window order (row-major over (i',j')) of kernel channel kc -> kr[0..n)
-    auto load_taps = [&](int kc, int first, int n) {
+    auto load_taps = [&](float (&kr)[KR][4], int kc, int first, int n) {
         const T* kb = kern + ((size_t)b * a.CK + kc) * (K * K) * kplane;
         if constexpr (!TRANSPOSED) {
             const T* kp = kb + (size_t)first * kplane + dpix;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T
         else store_quad<T, false>(op, x0, a.dst_w, acc);
     };
 
-    if (HOIST && live) load_taps(0, 0, K * K);
+    if (HOIST && live) load_taps(kr, 0, 0, K * K);
     fetch(c_begin);
     commit(0);
     __syncthreads();
@@ -291,13 +291,16 @@ __global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T
                 for (int cc = 0; cc < CB; ++cc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
+                // a shared kernel's tap rows are double-buffered: row i + 1 is requested before row i is applied
+                float kn[KR][4];
+                if (a.CK == 1) load_taps(kr, 0, 0, K);
 #pragma unroll 1
                 for (int i = 0; i < K; ++i) {
-                    if (a.CK == 1) load_taps(0, i * K, K);
+                    if (a.CK == 1 && i + 1 < K) load_taps(kn, 0, (i + 1) * K, K);
 #pragma unroll
                     for (int cc = 0; cc < CB; ++cc) {
                         if (c + cc < c_end) {
-                            if (a.CK != 1) load_taps(c + cc, i * K, K);
+                            if (a.CK != 1) load_taps(kr, c + cc, i * K, K);
                             float win[4 * NQUAD];
                             window(buf, cc, ly + i, win);
 #pragma unroll
@@ -305,6 +308,12 @@ __global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(kr[j][e], win[j + e], acc[cc][e]);
                         }
+                    }
+                    if (a.CK == 1 && i + 1 < K) {
+#pragma unroll
+                        for (int j = 0; j < K; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) kr[j][e] = kn[j][e];
                     }
                 }
 #pragma unroll
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256, (K > 5 ? 2 : 1)) void pac_conv2d_tiled(const T
 #pragma unroll
                 for (int cc = 0; cc < CB; ++cc) {
                     if (c + cc < c_end) {
-                        if (!HOIST) load_taps(a.CK == 1 ? 0 : c + cc, 0, K * K);
+                        if (!HOIST) load_taps(kr, a.CK == 1 ? 0 : c + cc, 0, K * K);
                         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll ROW_UNROLL
                         for (int i = 0; i < K; ++i) {
@@ -1249,6 +1258,18 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
     const dim3 grid(tiles, ceil_div(a.C, t.cchunk), a.B), block(256);
     constexpr bool CAN_HOIST = K <= 5;                   // the whole window in registers
     const bool hoist = CAN_HOIST && a.CK == 1;
+    if constexpr (K > 5) {
+        // a shared 7 x 7 kernel streams its 49 taps once per channel batch: batches of eight channels (101 KB of LDS, one
+        // workgroup per CU) halve that stream
+        if (a.CK == 1 && a.C >= 8) {
+            int nchunk8 = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, 8));
+            t.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk8, 1)), 8) * 8;
+            const dim3 grid8(tiles, ceil_div(a.C, t.cchunk), a.B);
+            pac_conv2d_tiled<T, K, false, 8, TRANSPOSED><<<grid8, block, 0, st>>>(src, kern, dst, t);
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     if (t.cchunk == 1) {
         if (hoist) pac_conv2d_tiled<T, K, CAN_HOIST, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
         else pac_conv2d_tiled<T, K, false, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
