@@ -73,7 +73,8 @@ if "weights" in sys.argv:
     x = x_keep
 if "stamps" in sys.argv:
     for T, SS in ((12, 4), (12, 6), (4, 4)):
-        rp = F.kres_plan(K, B, H, W, T, 0, 0, SS)
+        TH = int(os.environ.get("PT", 0))
+        rp = F.kres_plan(K, B, H, W, T, 0, 0, SS, TH)
         grid = rp["tiles_x"] * rp["tiles_y"] * min(B, rp["images_per_launch"])
         st = torch.zeros((grid, 16), dtype=torch.int64, device=dev)
         names = ["parked", "derive"]
@@ -82,17 +83,17 @@ if "stamps" in sys.argv:
         names[-1] = "epilogue"
         with torch.no_grad():
             for _ in range(3):
-                F.pac_forward_resident(g, x[:, 0].contiguous(), None, T, steps_per_phase=SS, debug_stamps=st)
+                F.pac_forward_resident(g, x[:, 0].contiguous(), None, T, steps_per_phase=SS, debug_stamps=st, threads=TH)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            F.pac_forward_resident(g, x[:, 0].contiguous(), None, T, steps_per_phase=SS, debug_stamps=st)
+            F.pac_forward_resident(g, x[:, 0].contiguous(), None, T, steps_per_phase=SS, debug_stamps=st, threads=TH)
             e1.record()
             e1.synchronize()
         t = st.cpu().numpy().astype("float64") / 100.0
         t0 = t[:, 0].min()
         print("T=%d S=%d plan %s; call (events) %.1f us; stamps are of the LAST launch (%d workgroups)" % (
-            T, SS, {k: rp[k] for k in ("tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread", "images_per_launch", "launches")},
+            T, SS, {k: rp[k] for k in ("tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread", "threads", "images_per_launch", "launches")},
             e0.elapsed_time(e1) * 1e3, grid))
         print("  workgroup start spread %.2f us" % (t[:, 0].max() - t0))
         for k in range(1, 16):
