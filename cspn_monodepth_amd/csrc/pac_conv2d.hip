@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_ti
     };
     float kr[KR][4];
     // taps [first, first+n) in window order (row-major over (i',j')) of kernel channel kc -> kr[0..n)
-    auto load_taps = [&](float (&kr)[KR][4], int kc, int first, int n) {
+    auto load_taps = [&](auto& kr, int kc, int first, int n) {
         const T* kb = kern + ((size_t)b * a.CK + kc) * (K * K) * kplane;
         if constexpr (!TRANSPOSED) {
             const T* kp = kb + (size_t)first * kplane + dpix;
@@ -291,16 +291,23 @@ __global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_ti
                 for (int cc = 0; cc < CB; ++cc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[cc][e] = 0.f;
-                // a shared kernel's tap rows are double-buffered: row i + 1 is requested before row i is applied
-                float kn[KR][4];
-                if (a.CK == 1) load_taps(kr, 0, 0, K);
+                // the eight-channel batches (always a shared kernel) double-buffer the tap rows: row i + 1 is requested before
+                // row i is applied.  Compile-time: the 28 extra registers cost the four-channel transposed instance its
+                // spill-free form.
+                constexpr bool PREF = CB == 8;
+                float kn[PREF ? KR : 1][4];
+                if (PREF) load_taps(kr, 0, 0, K);
 #pragma unroll 1
                 for (int i = 0; i < K; ++i) {
-                    if (a.CK == 1 && i + 1 < K) load_taps(kn, 0, (i + 1) * K, K);
+                    if constexpr (PREF) {
+                        if (i + 1 < K) load_taps(kn, 0, (i + 1) * K, K);
+                    } else {
+                        if (a.CK == 1) load_taps(kr, 0, i * K, K);
+                    }
 #pragma unroll
                     for (int cc = 0; cc < CB; ++cc) {
                         if (c + cc < c_end) {
-                            if (a.CK != 1) load_taps(kr, c + cc, i * K, K);
+                            if (!PREF && a.CK != 1) load_taps(kr, c + cc, i * K, K);
                             float win[4 * NQUAD];
                             window(buf, cc, ly + i, win);
 #pragma unroll
@@ -309,11 +316,13 @@ __global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_ti
                                 for (int e = 0; e < 4; ++e) acc[cc][e] = fmaf(kr[j][e], win[j + e], acc[cc][e]);
                         }
                     }
-                    if (a.CK == 1 && i + 1 < K) {
+                    if constexpr (PREF) {
+                        if (i + 1 < K) {
 #pragma unroll
-                        for (int j = 0; j < K; ++j)
+                            for (int j = 0; j < K; ++j)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) kr[j][e] = kn[j][e];
+                                for (int e = 0; e < 4; ++e) kr[j][e] = kn[j][e];
+                        }
                     }
                 }
 #pragma unroll

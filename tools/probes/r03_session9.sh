@@ -2,7 +2,7 @@
 # final evidence pass of round 3: full GPU suite, profile sessions (config 2 / 3), training legs, timelines, sweeps, bench lines
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r03s9
+O=$R/gpurun_out/${SESSION_TAG:-r03s9}
 mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
