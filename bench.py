@@ -270,6 +270,12 @@ def run_train(args, wl, world, rank, local_rank, device):
     # the reference's trainer sets cudnn.benchmark (main.py:37): MIOpen then picks every convolution algorithm by timing —
     # 36.5 -> 28.3 ms per step here, but ~8 minutes of searching on a fresh box (no tuning database travels), hence opt-in
     torch.backends.cudnn.benchmark = (args.conv_autotune == "on")
+    # ... and what that search found on an MI355X ships with the package (MIOpen's own find-db / perf-db files): immediate
+    # mode then picks the tuned solvers at once — 28.3 ms per step, no find phase in the first steps (--conv-db off: 36.6 ms)
+    conv_db = None
+    if args.conv_db == "shipped":
+        from cspn_monodepth_amd.network import conv_tuning
+        conv_db = conv_tuning.use_tuned_conv_db(rank=local_rank)
     torch.manual_seed(0)
     model = unet_cspn_nyu.resnet50(reference_state_dict=False, cspn_plan=parse_plan(args.plan)).to(device)
     if args.memory_format == "channels_last":      # stock-op layout choice only: the HIP ops take their planes contiguous
@@ -351,6 +357,8 @@ def run_train(args, wl, world, rank, local_rank, device):
                           "prop_time": wl["T"], "optimizer": "SGD(momentum 0.9, wd 1e-4)", "loss": "MaskedL1",
                           "parameters": int(sum(p.numel() for p in model.parameters())),
                           "conv_autotune": args.conv_autotune, "memory_format": args.memory_format,
+                          "conv_db": ("shipped (cspn_monodepth_amd/network/miopen_db)" if conv_db else
+                                      ("environment" if os.environ.get("MIOPEN_USER_DB_PATH") else "none")),
                           "parallelism": "DDP x%d over RCCL + SyncBatchNorm" % world if world > 1 else "single GPU"},
                "roofline": None,
                "cspn_module": {"forward_us_p50": med(fwd_us), "backward_us_p50": med(bwd_us),
@@ -373,6 +381,9 @@ def main():
     ap.add_argument("--workload", default="nyu", choices=sorted(WORKLOADS))
     ap.add_argument("--sparse", action="store_true", help="pass a 500-sample sparse depth (48 B/px/step)")
     ap.add_argument("--plan", default="", help="S,tile_w,tile_h,quads_per_thread,threads (default: built-in)")
+    ap.add_argument("--conv-db", choices=("shipped", "off"), default="shipped",
+                    help="--workload train: point MIOpen at the tuning database shipped with the package (the result of the "
+                         "reference's cudnn.benchmark search on an MI355X) unless MIOPEN_USER_DB_PATH is already set")
     ap.add_argument("--memory-format", default="contiguous", choices=("contiguous", "channels_last"),
                     help="--workload train: memory format of the stock convolution stack (NCHW as the reference, or NHWC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
