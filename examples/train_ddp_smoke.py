@@ -80,7 +80,8 @@ def main(argv=None):
     if args.model == "resnet50":
         if (args.H, args.W) != (228, 304):
             raise SystemExit("--model resnet50 uses the reference's 228x304 decoder pyramid (unet_cspn_nyu.py:327-332)")
-        from cspn_monodepth_amd.network import unet_cspn_nyu
+        from cspn_monodepth_amd.network import unet_cspn_nyu, use_tuned_conv_db
+        use_tuned_conv_db(local)            # where main.py:37 sets cudnn.benchmark: MIOpen reads the shipped result of that search
         model = unet_cspn_nyu.resnet50(reference_state_dict=False).to(device)
     else:
         model = TinyDepthNet().to(device)
