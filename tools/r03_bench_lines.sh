@@ -17,5 +17,7 @@ run kitti_b1 python bench.py --workload kitti --batch 1 --steps 200 --warmup 20 
 run nyu_b3 python bench.py --workload nyu --batch 3 --steps 200 --warmup 20 --no-cpu-baseline
 run pac5_b3 python bench.py --workload pac5 --batch 3 --steps 200 --warmup 20 --no-cpu-baseline --no-train-leg
 CSPN_RESIDENT=off run pac5_b3_multilaunch python bench.py --workload pac5 --batch 3 --steps 200 --warmup 20 --no-cpu-baseline --no-train-leg --no-per-step-leg --cold-sets 0
-run train_b3 python bench.py --workload train --steps 10 --warmup 3
+run train_b3 python bench.py --workload train --steps 30 --warmup 5
+run train_b3_graph python bench.py --workload train --steps 30 --warmup 5 --graph on
+run train_b3_round2_settings python bench.py --workload train --steps 30 --warmup 5 --conv-db off --sgd foreach
 for f in $O/*.json; do echo "$(basename $f): $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']), d['ms_per_step'], (d.get('training_step') or {}).get('fwd_bwd_us'))")"; done
