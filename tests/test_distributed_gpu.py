@@ -93,3 +93,21 @@ def test_rccl_process_group_world_size_one():
     assert out.returncode == 0
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["metrics_check"]["count"] > 0 and d["value"] > 0
+
+
+def test_bench_train_whole_step_graph_matches_eager():
+    """bench.py --workload train --graph on (one process): the whole optimiser step — stock convolutions, the un-pooling, both
+    weight-resident CSPN launches with their control-word memsets, the fused SGD — captured as ONE HIP graph; after the same
+    number of optimiser steps its loss equals the eager run's to the run-to-run noise of MIOpen's atomics."""
+    res = {}
+    for graph, warm in (("off", "9"), ("on", "3")):          # the graphed run adds 3 side-stream + 3 replayed warm-up steps
+        cmd = [sys.executable, "bench.py", "--workload", "train", "--steps", "6", "--warmup", warm, "--no-cpu-baseline",
+               "--graph", graph]
+        out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res[graph] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["on"]["config"]["hip_graph"] is True and res["off"]["config"]["hip_graph"] is False
+    assert res["on"]["optimiser_steps_run"] == res["off"]["optimiser_steps_run"] == 15
+    l_on, l_off = res["on"]["loss_first_last"], res["off"]["loss_first_last"]
+    assert l_on[0] == l_off[0]
+    assert l_off[1] < l_off[0] and abs(l_on[1] - l_off[1]) <= 5e-3 * l_off[1], (l_on, l_off)
