@@ -1,6 +1,8 @@
 // c_host_demo.cpp — the engine driven from plain C++ through the C ABI only (no PyTorch, no Python):
 //   hipMalloc / hipMemcpy, cspn3_propagate_from_guidance (the default inference path) and, for comparison, the
-//   two-call form cspn3_prepare + cspn_propagate; both results must be bit-identical.
+//   two-call form cspn3_prepare + cspn_propagate; both results must be bit-identical.  Where a tiling exists, also the
+//   weight-resident launch (cspn3_forward_resident: the schedule the Python host runs by default) with its whole host
+//   protocol — plan, zero-initialised workspace, growing sequence number, pinned error word — again bit-identical.
 //
 //   g++ -O2 -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ examples/c_host_demo.cpp \
 //       -L cspn_monodepth_amd -lcspn_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/cspn_monodepth_amd -o c_host_demo
@@ -74,9 +76,39 @@ int main(int argc, char** argv) {
         CHECK_HIP(hipMemcpy(ra.data(), out_a, plane * 4, hipMemcpyDeviceToHost));
         if (std::memcmp(ra.data(), rb.data(), plane * 4) != 0) { std::fprintf(stderr, "one-call and two-call results differ\n"); return 4; }
     }
+    // (c) the weight-resident launch: one launch per chunk of whole images, weights in registers for all T steps
+    bool resident = false;
+    cspn_resident_plan rp;
+    std::memset(&rp, 0, sizeof rp);
+    if (fused && cspn3_resident_plan(B, H, W, T, sparse ? 1 : 0, 0, &rp)) {
+        void* rwork;
+        unsigned* host_err;                                       // two pinned words the device writes: [0] time-out, [1] completion
+        float* out_c;
+        const size_t rbytes = cspn3_resident_workspace_bytes(B, H, W);
+        CHECK_HIP(hipMalloc(&rwork, rbytes));
+        CHECK_HIP(hipMemset(rwork, 0, rbytes));                   // once; afterwards only the sequence number grows
+        CHECK_HIP(hipHostMalloc((void**)&host_err, 2 * sizeof(unsigned), hipHostMallocMapped));
+        host_err[0] = host_err[1] = 0;
+        CHECK_HIP(hipMalloc((void**)&out_c, plane * 4));
+        unsigned seq = 256;
+        for (int call = 0; call < 2; ++call, seq += 256) {        // twice: the second call reuses the workspace of the first
+            CHECK_HIP(hipMemsetAsync(out_c, 0xff, plane * 4, st));
+            CHECK_CSPN(cspn3_forward_resident(g, (long)C * H * W, (long)H * W, d0, sp, out_c, nullptr, nullptr, nullptr, rwork, seq,
+                                              host_err, B, H, W, 0, T, blend, nullptr, nullptr, 0, &rp, st));
+            CHECK_HIP(hipStreamSynchronize(st));
+            if (host_err[0] != 0) { std::fprintf(stderr, "resident launch timed out (device shared?)\n"); return 5; }
+            std::vector<float> rc(plane);
+            CHECK_HIP(hipMemcpy(rc.data(), out_c, plane * 4, hipMemcpyDeviceToHost));
+            if (std::memcmp(rc.data(), rb.data(), plane * 4) != 0) { std::fprintf(stderr, "resident and multi-launch results differ (call %d)\n", call); return 4; }
+        }
+        resident = true;
+        std::printf("resident plan: %d-step phases, %dx%d tiles of %dx%d, %d quads/thread, %d image(s) per launch, %d launch(es)\n",
+                    rp.steps_per_phase, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.quads_per_thread, rp.images_per_launch, rp.launches);
+    }
     f = std::fopen(argv[2], "wb");
     if (!f || std::fwrite(rb.data(), sizeof(float), plane, f) != plane) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
     std::fclose(f);
-    std::printf("ok: %zu pixels, %d steps%s\n", plane, T, fused ? ", one-call == two-call bit for bit" : "");
+    std::printf("ok: %zu pixels, %d steps%s%s\n", plane, T, fused ? ", one-call == two-call bit for bit" : "",
+                resident ? ", resident == multi-launch bit for bit" : "");
     return 0;
 }

@@ -35,7 +35,8 @@ def test_c_host_demo_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,sparse", [((2, 12, 40, 64), True), ((1, 8, 33, 52), False), ((1, 8, 9, 13), True)])
+@pytest.mark.parametrize("shape,sparse", [((2, 12, 40, 64), True), ((1, 8, 33, 52), False), ((1, 8, 9, 13), True),
+                                          ((3, 12, 228, 304), True)])
 def test_c_host_demo_matches_oracle(tmp_path, shape, sparse):
     B, C, H, W = shape
     T = 24
@@ -53,3 +54,4 @@ def test_c_host_demo_matches_oracle(tmp_path, shape, sparse):
     assert rel_err(got, want) <= 1e-5
     if W % 4 == 0:
         assert "one-call == two-call" in run.stdout
+        assert "resident == multi-launch bit for bit" in run.stdout, run.stdout       # the default schedule, from plain C++
