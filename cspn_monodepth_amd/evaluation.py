@@ -123,14 +123,20 @@ def all_gather_metric_sums(sums, group=None, force_collective=False):
     This is where an evaluation loop hands its numbers on, so it first waits for the weight-resident launches that
     produced them and raises if one timed out (functional.ensure_resident_ok) — also for the last batch of the loop,
     which no later launch would check.  Returns (total [10], per_rank [world, 10]), independent tensors."""
+    initialised = dist.is_available() and dist.is_initialized()
+    if not initialised or (dist.get_world_size(group) == 1 and not force_collective):
+        # one rank: nothing to gather (force_collective: run the collective anyway — the world-size-1 RCCL test and bench.py's
+        # forced group).  The copies are enqueued BEHIND the launches first and the wait + check comes after: the same
+        # guarantee (nothing is returned from a timed-out launch), without two kernel launches into an idle queue
+        total = sums.sum(0) if sums.dim() == 2 else sums.clone()
+        per_rank = total.clone().unsqueeze(0)
+        if sums.is_cuda:
+            _F.ensure_resident_ok(sums.device)
+        return total, per_rank
     if sums.is_cuda:
         _F.ensure_resident_ok(sums.device)
     if sums.dim() == 2:
         sums = sums.sum(0)
-    initialised = dist.is_available() and dist.is_initialized()
-    if not initialised or (dist.get_world_size(group) == 1 and not force_collective):
-        total = sums.clone()                              # one rank: nothing to gather (force_collective: run the collective
-        return total, total.clone().unsqueeze(0)          # anyway — the world-size-1 RCCL test and bench.py's forced group)
     world = dist.get_world_size(group)
     src = sums.contiguous()
     if sums.is_cuda and dist.get_backend(group) == "gloo":
