@@ -184,8 +184,9 @@ struct TiledArgs {
     int tiles_x;
 };
 
-template <typename T, int K, bool HOIST, int CB, bool TRANSPOSED>
-__global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
+// NBUF = 1: the whole channel chunk is ONE batch (cchunk <= CB, the host's promise) — no second LDS buffer, twice the workgroups per CU
+template <typename T, int K, bool HOIST, int CB, bool TRANSPOSED, int NBUF = 2>
+__global__ __launch_bounds__(256, (K > 5 && (CB <= 4 || NBUF == 1) ? 2 : 1)) void pac_conv2d_tiled(const T* __restrict__ src, const T* __restrict__ kern,
                                                                          T* __restrict__ dst, TiledArgs a) {
     constexpr int RW = TILE_W + ((K - 1 + 3) & ~3);     // LDS row pitch, a multiple of 4
     constexpr int RH = TILE_H + K - 1;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_ti
     constexpr bool ROWWISE = K > 5;
     constexpr int KR = ROWWISE ? K : K * K;
     constexpr int ROW_UNROLL = ROWWISE ? 1 : K;         // row-wise: a real loop, or the tap loads are hoisted and spill
-    __shared__ __attribute__((aligned(16))) float tile[2][CB][PATCH];
+    __shared__ __attribute__((aligned(16))) float tile[NBUF][CB][PATCH];
     const int tid = blockIdx.x;
     const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
     const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_ti
     __syncthreads();
     int buf = 0;
     for (int c = c_begin; c < c_end; c += CB) {
-        const bool more = c + CB < c_end;
+        const bool more = NBUF > 1 && c + CB < c_end;
         if (more) fetch(c + CB);
         if (live) {
             if constexpr (ROWWISE) {
@@ -348,9 +349,9 @@ __global__ __launch_bounds__(256, (K > 5 && CB <= 4 ? 2 : 1)) void pac_conv2d_ti
                 }
             }
         }
-        if (more) commit(buf ^ 1);
+        if (more) commit((buf + 1) % NBUF);
         __syncthreads();
-        buf ^= 1;
+        buf = (buf + 1) % NBUF;
     }
 }
 
@@ -1274,7 +1275,8 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
             int nchunk8 = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, 8));
             t.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk8, 1)), 8) * 8;
             const dim3 grid8(tiles, ceil_div(a.C, t.cchunk), a.B);
-            pac_conv2d_tiled<T, K, false, 8, TRANSPOSED><<<grid8, block, 0, st>>>(src, kern, dst, t);
+            if (t.cchunk <= 8) pac_conv2d_tiled<T, K, false, 8, TRANSPOSED, 1><<<grid8, block, 0, st>>>(src, kern, dst, t);
+            else pac_conv2d_tiled<T, K, false, 8, TRANSPOSED><<<grid8, block, 0, st>>>(src, kern, dst, t);
             HIP_OK(hipGetLastError());
             return 1;
         }
@@ -1387,6 +1389,25 @@ int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
                 if (t.cchunk == 1) pac_conv2d_gk_window<T, K, false, 1><<<grid, block, 0, st>>>(g, in, gk, t);
                 else pac_conv2d_gk_window<T, K, false, CC><<<grid, block, 0, st>>>(g, in, gk, t);
             }
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
+    if constexpr (K == 7) {
+        // shared 7 x 7: the tap-row split below reads grad_out and the input seven times; with enough tiles the whole window
+        // (49 accumulator quads) stays in the registers of one workgroup instead
+        if (a.CK == 1 && (size_t)tiles * a.B >= 256) {
+            TiledArgs t{};
+            t.B = a.B; t.C = a.C; t.CK = a.CK;
+            t.src_h = a.H; t.src_w = a.W; t.dst_h = a.Ho; t.dst_w = a.Wo; t.k_h = a.Ho; t.k_w = a.Wo;
+            t.org_y = -a.ph; t.org_x = -a.pw;
+            t.k_vec = t.dst_vec = a.vec;
+            t.tiles_x = tiles_x;
+            t.cchunk = a.C;
+            const dim3 gridw(tiles, 1, a.B), blockw(256);
+            // one channel per batch: 247 VGPRs, two wavefronts per SIMD (two channels: 256 + spills to AGPRs, one wavefront —
+            // 67.8 vs 52.3 us; the tap-row split: 125.9 us)
+            pac_conv2d_gk_window<T, K, true, 1><<<gridw, blockw, 0, st>>>(g, in, gk, t);
             HIP_OK(hipGetLastError());
             return 1;
         }

@@ -219,6 +219,24 @@ def test_dilated_windows_full_frame_tiled_equals_generic(C, CK, k, p, d):
         assert nmax(g_, r_) <= 2e-6, (what, C, CK, k, p, d)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(4, 8, 228, 304), (4, 10, 228, 304), (16, 12, 128, 512), (4, 3, 228, 304)])
+def test_shared_7x7_with_many_tiles_tiled_equals_generic(B, C, H, W):
+    """A shared 7 x 7 kernel on launches with >= 256 tiles takes the eight-channel batches (one LDS buffer when the chunk is a
+    single batch, two when it is not: the 1024-tile case) and the whole-window dL/dkernel; fewer than eight channels keep the
+    four-channel kernel.  All of them against the scalar kernels."""
+    rng = np.random.default_rng(91)
+    K, p = 7, 3
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kern = (rng.standard_normal((B, 1, K, K, H, W)) * 0.2).astype(np.float32)
+    cot = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    with force_generic(0):
+        got = run_all(x, kern, cot, K, 1, p, 1)
+    with force_generic(1):
+        ref = run_all(x, kern, cot, K, 1, p, 1)
+    for g_, r_, what in zip(got, ref, ("out", "grad_input", "grad_kernel")):
+        assert nmax(g_, r_) <= 2e-6, (what, B, C, H, W)
+
+
 def test_padding_zero_times_nonfinite_kernel_is_nan_like_unfold():
     # F.unfold gives 0 in the padding and the reference multiplies it by the kernel: 0 * inf = NaN (pac.py:89-92)
     x = np.ones((1, 1, 4, 4), np.float32)
