@@ -15,12 +15,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
-HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
+SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
+HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(CSRC, "cspnk_helpers.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 6          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 7          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -43,7 +43,11 @@ class cspn_plan(ctypes.Structure):
 class cspn_resident_plan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("steps_per_phase", "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread",
                                             "threads", "images_per_launch", "launches", "lds_bytes", "n_cu")] + \
-               [("region_over_tile", ctypes.c_float), ("spin_limit", ctypes.c_uint), ("debug_stamps", ctypes.c_void_p)]
+               [("region_over_tile", ctypes.c_float), ("spin_limit", ctypes.c_uint), ("debug_stamps", ctypes.c_void_p),
+                ("step_form", ctypes.c_int)]
+
+
+STEP_AUTO, STEP_FMA, STEP_DOT2 = 0, 1, 2       # cspn_resident_plan.step_form (include/cspn_hip.h)
 
 
 class cspn_conv_geometry(ctypes.Structure):
@@ -93,12 +97,27 @@ def build(force=False, verbose=False):
     bdir = os.path.join(CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
 
+    import hashlib
+    hdr = hashlib.sha256(" ".join(flags[:-2]).encode())
+    for path in HEADERS:
+        with open(path, "rb") as fh:
+            hdr.update(fh.read())
+
     def compile_one(src):
+        # per-object staleness: flags + headers + this translation unit (an edit to one kernel recompiles one file)
         obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
+        h = hdr.copy()
+        with open(src, "rb") as fh:
+            h.update(fh.read())
+        want = h.hexdigest()
+        if not force and os.path.exists(obj) and os.path.exists(obj + ".hash") and open(obj + ".hash").read().strip() == want:
+            return obj
         cmd = [hipcc] + flags + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(obj + ".hash", "w") as fh:
+            fh.write(want + "\n")
         return obj
 
     with ThreadPoolExecutor(max_workers=len(srcs)) as pool:

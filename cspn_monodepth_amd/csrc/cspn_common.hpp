@@ -20,6 +20,10 @@ const char* last_error();
 int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, void* out, void* history, void* wk_out, void* work,
                       unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend, const void* target, double* acc,
                       int nslots, const cspn_resident_plan* plan, void* stream);
+// cspnk_d2.hip: the K = 5 fp16 form with the state packed as fp16 pairs in LDS and v_dot2_f32_f16 steps (launched by cspnk_forward_resident)
+int kres_d2_row_stride(int wo);
+size_t kres_d2_lds_bytes(int dr, int ls, int threads);
+int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int score, int clean, void* stream);
 }  // namespace cspn_detail
 
 namespace {

@@ -1,0 +1,506 @@
+// cspnk_d2.hip — BASELINE config 3's kernel: the 5 x 5 softmax propagation with fp16 guidance AND fp16 state as ONE
+// weight-resident launch whose steps run on v_dot2_f32_f16.
+//
+// Reference path: network/libs/post_process/CSPN_ours.py:24-54 (softmax over the 24 guidance channels :35, zero centre tap
+// :37-39, prop_time x { pac.conv2d :49 = network/libs/base/pac.py:89-92, sparse blend :51-53 }) run in half precision, where the
+// state x is a half tensor that is rounded after every step.
+//
+// cspnk_resident.hip keeps the state as fp32 in LDS and spends one v_fma_mix_f32 per tap and pixel: 192 per oct-step at 4.6 cycles
+// per wavefront (tools/probes/valu_rate_probe.hip) — the step phases were 2 x 17 of the 86 us of a forward.  Here
+//   * the state lives in LDS as PACKED fp16 pairs (what the reference's half tensor holds between steps): a window row of an oct is
+//     one ds_read_b128 + two ds_read_b32, the five odd-aligned pairs come from v_alignbit_b32;
+//   * the softmax taps are packed as TAP pairs of one pixel — (dx-2, dx-1), (dx, dx+1) of a window row — so that two taps are one
+//     v_dot2_f32_f16 (same issue cost as one v_fma_mix_f32, measured): 10 dot products + 4 single taps per pixel-step instead of
+//     24 FMAs, fp32 accumulation, ONE rounding to fp16 per step (v_cvt_pk_f16_f32);
+//   * the batch goes through ONE launch: the register files hold the taps of 12 of config 3's 24 frames, so a workgroup refines
+//     its tile of frame b and then of frame b + 12 back to back (a.rounds) — no second launch, no drain between the halves;
+//   * the softmax is cheaper per channel (max folded into the exponent's scale: one v_fma_mix_f32 + v_exp_f32; numerator x 1/sum
+//     rounded by v_mul_f32 + v_cvt_pk_f16_f32 for two taps at a time).
+// Results are those of the half-precision recurrence with fp32 accumulation inside a step; they differ from the phase-rounded
+// schedules of cspnk_resident.hip / the multi-launch plans by fp16 rounding of the state (tests: oracle tolerance of the fp16
+// configuration, tests/test_hip_kres.py).  Exchange protocol, flags, bounded wait and NaN poisoning: those of cspnk_resident.hip.
+#include "cspnk_helpers.hpp"
+
+#include <atomic>
+
+namespace {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned v4uu __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) v4uu* lds_cv4u_ptr;
+typedef const volatile __attribute__((address_space(3))) unsigned* lds_cu_ptr;
+
+__device__ __forceinline__ float dot2(unsigned w, unsigned x, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), __builtin_bit_cast(h2, x), acc, false);
+}
+// acc + half(WH of w) * half(XH of x): one v_fma_mix_f32 with both factors taken from packed halfs.  Written as C++ (the
+// backend folds the two conversions into the instruction), NOT as inline asm: a v_dot2c_f32_f16 result read by the very next
+// VALU instruction needs wait states that the hazard recogniser only inserts in front of instructions it can see — the asm
+// form read stale accumulators (tools/probes/d2_debug.py).  The step loop keeps the conversions from being hoisted out of the
+// loop (32 registers) by passing the single-tap registers through an empty asm once per step.
+template <int WH, int XH>
+__device__ __forceinline__ float mix_hh(unsigned w, unsigned x, float acc) {
+    const h2 wv = __builtin_bit_cast(h2, w), xv = __builtin_bit_cast(h2, x);
+    return __builtin_fmaf((float)wv[WH], (float)xv[XH], acc);
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {      // round to nearest even, both halves in one instruction (gfx950)
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// half(HF of w) * scale + add, as ONE v_fma_mix_f32: the softmax exponent's argument (v - max) * log2(e) with a single rounding
+template <int HF>
+__device__ __forceinline__ float half_scaled(unsigned w, float scale, float add) {
+    float out;
+    if constexpr (HF != 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(scale), "v"(add));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(scale), "v"(add));
+    return out;
+}
+
+// Tap-pair slots of one pixel (12 registers): window row rr = dy + 2, channel c of tap (dy, dx) = lin < 12 ? lin : lin - 1 with
+// lin = 5 rr + dx + 2 (CSPN_ours.py:35-39: the 24 channels are the taps in row-major order without the centre).
+//   slot 2 rr, 2 rr + 1 (rr = 0, 1)        : (dx -2, -1), (dx 0, +1)          slot 10: single dx +2 of rows 0 (low half), 1 (high)
+//   slot 4, 5 (centre row)                  : (dx -2, -1), (dx +1, +2)
+//   slot 6 + 2 (rr - 3), 7 + 2 (rr - 3)     : (dx -2, -1), (dx 0, +1)          slot 11: single dx +2 of rows 3 (low half), 4 (high)
+constexpr int D2_LO[12] = {0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 4, 18};
+constexpr int D2_HI[12] = {1, 3, 6, 8, 11, 13, 15, 17, 20, 22, 9, 23};
+
+// softmax over the 24 channels of ONE pixel (half HF of the 24 packed words) -> its 12 tap-pair registers.  nmx = -max * log2(e).
+template <int HF>
+__device__ __forceinline__ void softmax_to_pairs(const unsigned (&w)[24], float nmx, unsigned (&out)[12]) {
+    constexpr float L2E = 1.44269502162933349609375f;
+    float v[24];
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) {
+        v[c] = __builtin_amdgcn_exp2f(half_scaled<HF>(w[c], L2E, nmx));
+        den += v[c];                                          // channel order, as every softmax of the engine
+    }
+    const float inv = reciprocal_refined(den);
+#pragma unroll
+    for (int s = 0; s < 12; ++s) out[s] = cvt_pk_f16(v[D2_LO[s]] * inv, v[D2_HI[s]] * inv);
+}
+
+constexpr int D2_R = 2, D2_NT = 24;
+
+template <int BLEND, int SCORE, int CLEAN, int NTH>
+__global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
+    constexpr int R = D2_R, NT = D2_NT;
+    using IO = StateIO<__half>;
+    using Oct = IO::Oct;
+    using Pair = IO::Pair;
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];
+    __shared__ int wg_bad;
+
+    const int tid = threadIdx.x;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int tile = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int bl = tile / tiles_per_img;
+    const int trem = tile - bl * tiles_per_img;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int H = a.H, W = a.W;
+    const int y0 = ty * a.th, x0 = tx * a.tw;
+    const unsigned HW = (unsigned)(H * W);
+    const size_t plane = (size_t)a.B * HW;
+    int n_stamp = 0;
+
+    // ---- ownership: thread (sy, sx) owns oct sx of region row sy (tile + halo), one oct per thread ---------------------
+    const int wo = a.wo, wr = a.wr;
+    const int sy = tid / wo;
+    const int sx = tid - sy * wo;
+    const bool exch = a.T > a.S;
+    const int rx0 = max(exch ? max(0, x0 - a.tw) : 0, min(x0 - a.hxw, W - 8 * wo));
+    const int ry0 = max(exch ? max(0, y0 - a.th) : 0, min(y0 - a.hyw, H - wr));
+    const int xo = rx0 + 8 * sx;
+    const int yo = ry0 + sy;
+    const bool active = sy < wr;
+    const bool in_img = active && xo < W && yo < H;        // W % 8 == 0: an oct is inside the image or outside as a whole
+    const bool interior = in_img && yo >= y0 && yo < y0 + a.th && xo >= x0 && xo < x0 + a.tw;
+    const unsigned off_own = in_img ? (unsigned)(yo * W + xo) : 0u;
+
+    // LDS: two depth buffers of dr rows x ls dwords; a row is [3 pad][ring pair][wo octs x 4 dwords][ring pair][pad]: oct k at
+    // dword 4 (k + 1) (16-byte aligned), the pixel pair left of the row at dword 3, the pair right of it at dword 4 (wo + 1)
+    const int dr = a.dr, ls = a.ls;
+    const int pp = dr * ls;
+    const int yd0 = ry0 - R;
+    const int step_r = NTH / wo, step_q = NTH - step_r * wo;
+    const int n_phase = (a.T + a.S - 1) / a.S;
+
+    for (int round = 0; round < a.rounds; ++round) {
+        const int b = a.b0 + round * a.nb + bl;
+        if (b >= a.B) break;                                  // the last round of a ragged batch has fewer images
+        auto stamp = [&]() {
+            if (a.dbg && tid == 0 && n_stamp < 16 && round == a.rounds - 1) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64();
+        };
+        if (round > 0) __syncthreads();                       // the previous round's readers of LDS are done
+        if (tid == 0) wg_bad = 0;
+        stamp();
+        const __half* __restrict__ x0b = kuniform_ptr(static_cast<const __half*>(a.x0) + (size_t)b * HW);
+        const __half* __restrict__ spb = BLEND ? kuniform_ptr(static_cast<const __half*>(a.sparse) + (size_t)b * HW) : nullptr;
+
+        // ---- 0. the depth region of phase 0 is requested FIRST (loads return in order) ---------------------------------
+        Oct st0[2];                                           // dr * wo <= 2 * NTH octs (the host checks)
+        unsigned st0_in = 0;
+        {
+            int row = sy, oc = sx;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int y = yd0 + row, x = rx0 + 8 * oc;
+                const bool in = (row < dr) && y >= 0 && y < H && x < W;
+                if (in) st0_in |= 1u << u;
+                st0[u] = IO::ld_oct(x0b, in ? (unsigned)(y * W + x) : 0u);
+                row += step_r; oc += step_q;
+                if (oc >= wo) { oc -= wo; ++row; }
+            }
+        }
+        Pair rg[2];
+        unsigned rg_in = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = tid + k * NTH;
+            const int row = t >> 1, side = t & 1;
+            const int y = yd0 + row, x = side ? rx0 + 8 * wo : rx0 - 2;
+            const bool in = (t < 2 * dr) && y >= 0 && y < H && x >= 0 && x < W;
+            if (in) rg_in |= 1u << k;
+            rg[k] = IO::ld_pair(x0b, in ? (unsigned)(y * W + x) : 0u);
+        }
+
+        // ---- 1. guidance of the owned oct: 24 16-byte loads, all requested before the arithmetic ----------------------
+        uint4 graw[NT];
+        const __half* __restrict__ gb = kuniform_ptr(static_cast<const __half*>(a.g) + (size_t)b * NT * HW);
+        // (an opaque per-round copy of the offset: left loop-invariant, the 24 load addresses are hoisted out of the round loop as
+        // 64-bit pairs, spilled, and every scratch reload between the loads waits for the whole in-order stream)
+        unsigned off_r = off_own;
+        asm volatile("" : "+v"(off_r));
+#pragma unroll
+        for (int c = 0; c < NT; ++c) graw[c] = ld16(atb(gb, ((unsigned)c * HW + off_r) * 2u));
+        // sparse blend operands of the owned oct, behind the guidance
+        Oct spo, x0o;
+        if (BLEND) { spo = IO::ld_oct(spb, off_r); x0o = IO::ld_oct(x0b, off_r); }
+
+        // ---- park the depth region (its loads came first: only those are waited for here) ------------------------------
+        unsigned* const cur = ldsu;
+        unsigned* const nxt = ldsu + pp;
+        {
+            int tidk = tid, prow = sy, poc = sx;
+            asm volatile("" : "+v"(tidk), "+v"(prow), "+v"(poc));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool in = (st0_in >> u) & 1u;
+                if (prow < dr) {
+                    const uint4 v = st0[u].a;
+                    *reinterpret_cast<uint4*>(cur + prow * ls + 4 * (poc + 1)) = make_uint4(in ? v.x : 0u, in ? v.y : 0u, in ? v.z : 0u, in ? v.w : 0u);
+                }
+                prow += step_r; poc += step_q;
+                if (poc >= wo) { poc -= wo; ++prow; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = tidk + k * NTH;
+                if (t < 2 * dr) {
+                    const int row = t >> 1, side = t & 1;
+                    const bool in = (rg_in >> k) & 1u;
+                    const int at = row * ls + (side ? 4 * (wo + 1) : 3);
+                    cur[at] = in ? rg[k].a : 0u;
+                    nxt[at] = 0u;                              // the ring of the second buffer is never computed: it must read as 0
+                }
+            }
+            // ... and so must its ring ROWS (with shifted regions they are the zero padding above / below the image)
+            for (int c = tidk; c < 2 * R * ls; c += NTH) {
+                const int rr = c / ls, col = c - rr * ls;
+                nxt[(rr < R ? rr : dr - 2 * R + rr) * ls + col] = 0u;
+            }
+        }
+        stamp();                                              // depth region parked
+
+        // ---- 2. softmax of the 8 owned pixels -> tap-pair registers -----------------------------------------------------
+        unsigned wq[8][12];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned w[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) w[c] = comp(graw[c], q);
+            unsigned mx2 = 0xfc00fc00u;                       // (-inf, -inf): the channel maximum of both pixels at once (exact)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) mx2 = pk_max_f16(mx2, w[c]);
+            constexpr float L2E = 1.44269502162933349609375f;
+            softmax_to_pairs<0>(w, -h2f_lo(mx2) * L2E, wq[2 * q]);
+            softmax_to_pairs<1>(w, -h2f_hi(mx2) * L2E, wq[2 * q + 1]);
+        }
+        // sparse blend (CSPN_ours.py:51-53): (1-m) u + m x0, m = sign(sparse); 1-m in {0, 1, 2} is folded into the taps (exact in
+        // fp16), the steps start their sums from md = m x0
+        float md[BLEND ? 8 : 1];
+        if (BLEND) {
+            float sp[8], dv[8];
+            IO::to_f8(spo, sp);
+            IO::to_f8(x0o, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float m = in_img ? sgnf(sp[e]) : 0.f;
+                md[e] = m * (in_img ? dv[e] : 0.f);
+                const unsigned om = pack_h2(1.f - m, 1.f - m);
+#pragma unroll
+                for (int s = 0; s < 12; ++s) wq[e][s] = pk_mul_f16(wq[e][s], om);
+            }
+        }
+        stamp();                                              // weights derived
+
+        // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes --------------------
+        __half* __restrict__ outb = kuniform_ptr(static_cast<__half*>(a.out) + (size_t)b * HW);
+        const int tile_global = b * tiles_per_img + trem;
+        uint4 fin = make_uint4(0u, 0u, 0u, 0u);               // the final step's packed result (scored after the loop)
+        bool aborted = false;
+
+        for (int p = 0; p < n_phase; ++p) {
+            const int steps = (a.T - p * a.S) < a.S ? (a.T - p * a.S) : a.S;
+            const bool last_phase = (p == n_phase - 1);
+            __half* __restrict__ xout = kuniform_ptr(static_cast<__half*>(a.xbuf) + (size_t)(p & 1) * plane + (size_t)b * HW);
+            if (p > 0) {
+                // halo octs only (the tile's own interior is in LDS already), device-scope loads, two per thread and trip
+                const __half* __restrict__ xin = kuniform_ptr(static_cast<const __half*>(a.xbuf) + (size_t)((p + 1) & 1) * plane + (size_t)b * HW);
+                const int tq_in = min(a.tw, rx0 + 8 * wo - x0) >> 3;
+                const int th_in = min(a.th, ry0 + wr - y0);
+                const int nl = (x0 - rx0) >> 3;
+                const int nside = wo - tq_in;
+                const int nrow_t = (y0 - ry0) + R;
+                const int n_top = nrow_t * wo;
+                const int n_bot = (dr - nrow_t - th_in) * wo;
+                const int n_halo = n_top + n_bot + th_in * nside;
+                Pair rgp[2];
+                unsigned rgp_in = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int t = tid + k * NTH;
+                    const int row = t >> 1, side = t & 1;
+                    const int y = yd0 + row, x = side ? rx0 + 8 * wo : rx0 - 2;
+                    const bool in = (t < 2 * dr) && y >= 0 && y < H && x >= 0 && x < W;
+                    if (in) rgp_in |= 1u << k;
+                    rgp[k] = IO::ld_pair_dev(xin, in ? (unsigned)(y * W + x) : 0u);
+                }
+                for (int base = 0; base < n_halo; base += 2 * NTH) {
+                    Oct hv[2];
+                    int at[2];
+                    bool hin[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int h = base + u * NTH + tid;
+                        int row, oc;
+                        if (h < n_top) { row = h / wo; oc = h - row * wo; }
+                        else if (h < n_top + n_bot) { const int h2 = h - n_top; row = h2 / wo; oc = h2 - row * wo; row += nrow_t + th_in; }
+                        else {
+                            const int h3 = h - n_top - n_bot;
+                            const int ns = nside > 0 ? nside : 1;
+                            row = h3 / ns;
+                            const int c = h3 - row * ns;
+                            row += nrow_t;
+                            oc = c < nl ? c : c + tq_in;
+                        }
+                        const int y = yd0 + row, x = rx0 + 8 * oc;
+                        const bool valid = h < n_halo;
+                        hin[u] = valid && y >= 0 && y < H && x < W;
+                        hv[u] = IO::ld_oct_dev(xin, hin[u] ? (unsigned)(y * W + x) : 0u);
+                        at[u] = valid ? row * ls + 4 * (oc + 1) : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (at[u] >= 0) {
+                            const uint4 v = hv[u].a;
+                            const bool in = hin[u];
+                            *reinterpret_cast<uint4*>(cur + at[u]) = make_uint4(in ? v.x : 0u, in ? v.y : 0u, in ? v.z : 0u, in ? v.w : 0u);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int t = tid + k * NTH;
+                    if (t < 2 * dr) {
+                        const int row = t >> 1, side = t & 1;
+                        const bool in = (rgp_in >> k) & 1u;
+                        cur[row * ls + (side ? 4 * (wo + 1) : 3)] = in ? rgp[k].a : 0u;
+                    }
+                }
+            }
+            __syncthreads();
+            stamp();                                          // depth staged
+
+            // One propagation step on the packed LDS tile: kind 0 = plain, 1 = last step of a phase (the interior is published),
+            // 2 = the final step of the forward (refined depth stored, kept for scoring).
+            auto step = [&](const int kind, const unsigned* rd, unsigned* wrb) __attribute__((always_inline)) {
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(wq[e][10]), "+v"(wq[e][11]));      // see mix_hh
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = BLEND ? md[BLEND ? e : 0] : 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 2 * R + 1; ++rr) {
+                    int drow = sy + rr;                       // depth-region row of window row rr; idle threads past the region read
+                    drow = drow < dr ? drow : dr - 1;         // the clamped last row and never store
+                    const unsigned* rowp = rd + drow * ls + 4 * (sx + 1);
+                    unsigned D[6], U[5];
+                    const v4uu d4 = *(lds_cv4u_ptr)(rowp);
+                    D[0] = *(lds_cu_ptr)(rowp - 1);
+                    D[5] = *(lds_cu_ptr)(rowp + 4);
+                    D[1] = d4.x; D[2] = d4.y; D[3] = d4.z; D[4] = d4.w;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) U[k] = __builtin_amdgcn_alignbit(D[k + 1], D[k], 16);      // pixels (2k - 1, 2k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float& ae = acc[2 * q];
+                        float& ao = acc[2 * q + 1];
+                        const unsigned (&we)[12] = wq[2 * q];
+                        const unsigned (&wo_)[12] = wq[2 * q + 1];
+                        if (rr == 2) {
+                            ae = dot2(we[4], D[q], ae);       ae = dot2(we[5], U[q + 1], ae);
+                            ao = dot2(wo_[4], U[q], ao);      ao = dot2(wo_[5], D[q + 2], ao);
+                        } else {
+                            const int s0 = rr < 2 ? 2 * rr : 6 + 2 * (rr - 3);
+                            ae = dot2(we[s0], D[q], ae);      ae = dot2(we[s0 + 1], D[q + 1], ae);
+                            ao = dot2(wo_[s0], U[q], ao);     ao = dot2(wo_[s0 + 1], U[q + 1], ao);
+                            if (rr == 0) { ae = mix_hh<0, 0>(we[10], D[q + 2], ae); ao = mix_hh<0, 1>(wo_[10], D[q + 2], ao); }
+                            if (rr == 1) { ae = mix_hh<1, 0>(we[10], D[q + 2], ae); ao = mix_hh<1, 1>(wo_[10], D[q + 2], ao); }
+                            if (rr == 3) { ae = mix_hh<0, 0>(we[11], D[q + 2], ae); ao = mix_hh<0, 1>(wo_[11], D[q + 2], ao); }
+                            if (rr == 4) { ae = mix_hh<1, 0>(we[11], D[q + 2], ae); ao = mix_hh<1, 1>(wo_[11], D[q + 2], ao); }
+                        }
+                    }
+                }
+                uint4 o = make_uint4(cvt_pk_f16(acc[0], acc[1]), cvt_pk_f16(acc[2], acc[3]), cvt_pk_f16(acc[4], acc[5]), cvt_pk_f16(acc[6], acc[7]));
+                if (!CLEAN) { if (!in_img) o = make_uint4(0u, 0u, 0u, 0u); }        // zero padding stays exactly zero
+                if (kind == 1) { if (interior) st16_dev(xout, off_own * 2u, o); }
+                else if (kind == 2) { if (interior) st16(atb(outb, off_own * 2u), o); fin = o; }
+                if (kind != 2 && active) *reinterpret_cast<uint4*>(wrb + (sy + R) * ls + 4 * (sx + 1)) = o;
+            };
+            const bool any = __ballot(active) != 0ull;       // wavefronts without a single owned row only keep the barriers company
+            for (int s = 0; s < steps; ++s) {
+                const int kind = (s == steps - 1) ? (last_phase ? 2 : 1) : 0;
+                if (any) step(kind, ldsu + (s & 1) * pp, ldsu + ((s + 1) & 1) * pp);
+                if (kind == 0) __syncthreads();
+            }
+            stamp();                                          // steps of the phase done
+            if (!last_phase) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's device-scope stores have landed
+                __syncthreads();                                       // ... and so have everybody else's in the workgroup
+                const unsigned want = a.seq + (unsigned)p + 1u;
+                if (tid == 0) __hip_atomic_store(a.flags + tile_global, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid < 9 && tid != 4) {
+                    const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                    if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
+                        const unsigned* f = a.flags + b * tiles_per_img + ny * a.tiles_x + nx;
+                        unsigned spins = 0;
+                        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                            ++spins;
+                            if ((spins & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
+                                wg_bad = 1;
+                                break;
+                            }
+                            if (spins > a.spin_limit) {                // a neighbour never became resident / finished: give up
+                                __hip_atomic_store(a.status, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                wg_bad = 1;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                }
+                __syncthreads();
+                stamp();                                      // neighbours' borders published
+                if (wg_bad) { aborted = true; break; }
+            }
+        }
+        if (aborted) {
+            if (tid == 0) {
+                __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            }
+            // poison what this workgroup will never produce — this round's tile and the tiles of its remaining rounds — with NaN
+            const uint4 qn = make_uint4(0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u);
+            for (int r2 = round; r2 < a.rounds; ++r2) {
+                const int b2 = a.b0 + r2 * a.nb + bl;
+                if (b2 < a.B && interior) st16(atb(static_cast<__half*>(a.out) + (size_t)b2 * HW, off_own * 2u), qn);
+            }
+            return;
+        }
+        if (SCORE) {
+            float mf[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) mf[k] = 0.f;
+            if (interior) {
+                const __half* tgt_b = kuniform_ptr(static_cast<const __half*>(a.target) + (size_t)b * HW);
+                float t8[8], f8[8];
+                IO::to_f8(IO::ld_oct(tgt_b, off_own), t8);
+                IO::to_f8(Oct{fin}, f8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) metric_terms(f8[e], t8[e], mf);
+            }
+            float* part = reinterpret_cast<float*>(ldsu + 2 * pp);
+            const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const float v = wave_sum_to_lane63(mf[k]);
+                if (lane == 63) part[wave * 10 + k] = v;
+            }
+            __syncthreads();
+            if (tid < 10) {
+                double v = 0.0;
+                for (int w = 0; w < NTH / 64; ++w) v += (double)part[w * 10 + tid];
+                if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + tid, v);
+            }
+        }
+        stamp();                                              // epilogue done
+    }
+}
+
+template <int BLEND, int SCORE, int CLEAN, int NTH>
+int d2_launch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
+    constexpr auto kern = cspnk_d2<BLEND, SCORE, CLEAN, NTH>;
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (lds_bytes > 64 * 1024 && granted[dev & 63].load(std::memory_order_acquire) < lds_bytes) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        granted[dev & 63].store(lds_bytes, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds_bytes, st, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+template <int NTH>
+int d2_launch_nth(const KResArgs& a, int grid, size_t lds, int blend, int score, int clean, hipStream_t st) {
+#define D2_CASE(BL, SC, CL) \
+    if (blend == BL && score == SC && clean == CL) return d2_launch_inst<BL, SC, CL, NTH>(a, grid, lds, st)
+    D2_CASE(0, 0, 0); D2_CASE(0, 0, 1); D2_CASE(0, 1, 0); D2_CASE(0, 1, 1);
+    D2_CASE(1, 0, 0); D2_CASE(1, 0, 1); D2_CASE(1, 1, 0); D2_CASE(1, 1, 1);
+#undef D2_CASE
+    return fail("cspnk_forward_resident (dot2 form): internal dispatch");
+}
+
+}  // namespace
+
+namespace cspn_detail {
+
+// Row stride (dwords) of a packed depth buffer: [3 pad][ring pair][wo octs][ring pair] rounded up to whole quads, and such that the
+// 16-byte slot a lane reads continues the bank pattern of the row above it inside a wavefront: ls = 4 wo (mod 64 dwords).
+int kres_d2_row_stride(int wo) {
+    const int lo = 4 * (wo + 2);
+    int best = lo, best_score = 1 << 30;
+    for (int cand = lo; cand < lo + 64; cand += 4) {
+        const int score = (((cand - 4 * wo) % 64) + 64) % 64;
+        if (score < best_score) { best_score = score; best = cand; }
+    }
+    return best;
+}
+
+size_t kres_d2_lds_bytes(int dr, int ls, int threads) {
+    return ((size_t)2 * dr * ls + (size_t)(threads / 64) * 10 + 16) * sizeof(unsigned);
+}
+
+int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int score, int clean, void* stream) {
+    const KResArgs& a = *static_cast<const KResArgs*>(kres_args);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (threads == 768) return d2_launch_nth<768>(a, grid, lds_bytes, blend, score, clean, st);
+    if (threads == 512) return d2_launch_nth<512>(a, grid, lds_bytes, blend, score, clean, st);
+    return fail("cspnk_forward_resident (dot2 form): %d threads (512 or 768)", threads);
+}
+
+}  // namespace cspn_detail

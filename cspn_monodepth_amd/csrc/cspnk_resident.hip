@@ -23,176 +23,11 @@
 // Register budget: 24 taps x 4 = 96 VGPRs per oct; NO = 2 at 512 threads (2 wavefronts per SIMD, 256 VGPRs).  The tap volume of
 // config 3 (80 MB) does not fit the chip's register files with its halo (131 MB in all), so the batch goes through two
 // launches of 12 images (20 tiles each); see DESIGN.md §4.1c for the arithmetic.
-#include "cspn_common.hpp"
+#include "cspnk_helpers.hpp"
 
 #include <atomic>
 
 namespace {
-
-struct KResArgs {
-    const void* g;           // guided [B, K*K-1, H, W] f16 or f32 (GT)
-    const void* x0;          // [B,H,W] ST: the coarse depth
-    const void* sparse;      // [B,H,W] ST or null
-    void* out;               // [B,H,W] ST
-    void* xbuf;              // exchange planes [2][B,H,W] ST (workspace)
-    unsigned* flags;         // [B * tiles_per_img] phase flags
-    unsigned* status;        // [0] abort, [1] sticky error, [2] count-out counter
-    unsigned* host_err;      // optional two host-mapped words (error, completion: include/cspn_hip.h)
-    unsigned seq;
-    const void* target;      // SCORE: [B,H,W] ST
-    double* macc;
-    int nslots;
-    int B, H, W, T, S;
-    int tw, th, tiles_x, tiles_y;
-    int wo, wr, hxw, hyw, dr, ls;
-    int b0, nb, last_chunk;
-    unsigned spin_limit;
-    unsigned long long* dbg;  // developer probe: [grid][16] wall-clock stamps (100 MHz) per workgroup, or null
-};
-
-#define GLB __attribute__((address_space(1)))
-typedef GLB char* gptr;
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const volatile __attribute__((address_space(3))) v2f* lds_cv2f_ptr;
-typedef const volatile __attribute__((address_space(3))) float* lds_cf_ptr;
-
-template <typename T>
-__device__ __forceinline__ T* kuniform_ptr(T* p) {      // a wave-uniform pointer, pinned to an SGPR pair
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-// SGPR base + 32-bit BYTE offset, typed as a global (address space 1) pointer: no 64-bit address arithmetic, no flat loads
-__device__ __forceinline__ gptr atb(const void* base, unsigned byte_off) {
-    return (gptr) reinterpret_cast<unsigned long long>(base) + byte_off;
-}
-__device__ __forceinline__ uint4 ld16(gptr p) {
-    const v4u v = *reinterpret_cast<const GLB v4u*>(p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st16(gptr p, uint4 v) {
-    const v4u w = {v.x, v.y, v.z, v.w};
-    *reinterpret_cast<GLB v4u*>(p) = w;
-}
-__device__ __forceinline__ unsigned ld4u(gptr p) { return *reinterpret_cast<const GLB unsigned*>(p); }
-__device__ __forceinline__ uint2 ld8u(gptr p) {
-    const v2u v = *reinterpret_cast<const GLB v2u*>(p);
-    return make_uint2(v.x, v.y);
-}
-// device-scope (sc1) accesses: coherent across the XCDs' private L2s without cache-wide write-back / invalidate
-__device__ __forceinline__ uint4 ld16_dev(gptr p) {
-    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
-}
-__device__ __forceinline__ uint2 ld8u_dev(gptr p) {
-    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint2((unsigned)lo, (unsigned)(lo >> 32));
-}
-__device__ __forceinline__ unsigned ld4u_dev(gptr p) {
-    return __hip_atomic_load(reinterpret_cast<const GLB unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st16_dev(const void* base, unsigned byte_off, uint4 v) {
-    // ONE 16-byte device-scope store (the compiler only offers <= 8-byte atomics; two of them touch every line twice)
-    const v4u w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(w), "s"(base) : "memory");
-}
-
-__device__ __forceinline__ float h2f_lo(unsigned w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xffffu))); }
-__device__ __forceinline__ float h2f_hi(unsigned w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
-__device__ __forceinline__ unsigned f2h_bits(float v) { return (unsigned)__half_as_ushort(__float2half_rn(v)); }
-__device__ __forceinline__ unsigned pack_h2(float lo, float hi) { return f2h_bits(lo) | (f2h_bits(hi) << 16); }
-
-// The depth planes of a call are fp16 or fp32: an OCT (8 pixels of a row) is one or two 16-byte accesses, a PAIR (the two
-// ring pixels left / right of a region row) one 4- or 8-byte access.
-template <typename ST> struct StateIO;
-template <> struct StateIO<__half> {
-    struct Oct { uint4 a; };
-    struct Pair { unsigned a; };
-    static __device__ __forceinline__ Oct ld_oct(const void* b, unsigned e) { return Oct{ld16(atb(b, e * 2u))}; }
-    static __device__ __forceinline__ Oct ld_oct_dev(const void* b, unsigned e) { return Oct{ld16_dev(atb(b, e * 2u))}; }
-    static __device__ __forceinline__ Pair ld_pair(const void* b, unsigned e) { return Pair{ld4u(atb(b, e * 2u))}; }
-    static __device__ __forceinline__ Pair ld_pair_dev(const void* b, unsigned e) { return Pair{ld4u_dev(atb(b, e * 2u))}; }
-    static __device__ __forceinline__ void to_f8(const Oct& o, float (&v)[8]) {
-        v[0] = h2f_lo(o.a.x); v[1] = h2f_hi(o.a.x); v[2] = h2f_lo(o.a.y); v[3] = h2f_hi(o.a.y);
-        v[4] = h2f_lo(o.a.z); v[5] = h2f_hi(o.a.z); v[6] = h2f_lo(o.a.w); v[7] = h2f_hi(o.a.w);
-    }
-    static __device__ __forceinline__ void to_f2(const Pair& p, float& a, float& b) { a = h2f_lo(p.a); b = h2f_hi(p.a); }
-    static __device__ __forceinline__ Oct from_f8(const float (&v)[8]) {
-        return Oct{make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]))};
-    }
-    static __device__ __forceinline__ void st_oct(void* b, unsigned e, const Oct& o) { st16(atb(b, e * 2u), o.a); }
-    static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 2u, o.a); }
-};
-template <> struct StateIO<float> {
-    struct Oct { uint4 a, b; };
-    struct Pair { uint2 a; };
-    static __device__ __forceinline__ Oct ld_oct(const void* b, unsigned e) { return Oct{ld16(atb(b, e * 4u)), ld16(atb(b, e * 4u + 16u))}; }
-    static __device__ __forceinline__ Oct ld_oct_dev(const void* b, unsigned e) { return Oct{ld16_dev(atb(b, e * 4u)), ld16_dev(atb(b, e * 4u + 16u))}; }
-    static __device__ __forceinline__ Pair ld_pair(const void* b, unsigned e) { return Pair{ld8u(atb(b, e * 4u))}; }
-    static __device__ __forceinline__ Pair ld_pair_dev(const void* b, unsigned e) { return Pair{ld8u_dev(atb(b, e * 4u))}; }
-    static __device__ __forceinline__ void to_f8(const Oct& o, float (&v)[8]) {
-        v[0] = __uint_as_float(o.a.x); v[1] = __uint_as_float(o.a.y); v[2] = __uint_as_float(o.a.z); v[3] = __uint_as_float(o.a.w);
-        v[4] = __uint_as_float(o.b.x); v[5] = __uint_as_float(o.b.y); v[6] = __uint_as_float(o.b.z); v[7] = __uint_as_float(o.b.w);
-    }
-    static __device__ __forceinline__ void to_f2(const Pair& p, float& a, float& b) { a = __uint_as_float(p.a.x); b = __uint_as_float(p.a.y); }
-    static __device__ __forceinline__ Oct from_f8(const float (&v)[8]) {
-        return Oct{make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])),
-                   make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]))};
-    }
-    static __device__ __forceinline__ void st_oct(void* b, unsigned e, const Oct& o) { st16(atb(b, e * 4u), o.a); st16(atb(b, e * 4u + 16u), o.b); }
-    static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 4u, o.a); st16_dev(b, e * 4u + 16u, o.b); }
-};
-
-__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
-    unsigned r;
-    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ unsigned pk_max_f16(unsigned a, unsigned b) {
-    unsigned r;
-    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// float(half `hi ? high : low` of w) + f, as ONE v_fma_mix_f32 (half * 1.0 + float): exact product, one rounding
-__device__ __forceinline__ float half_plus_float(unsigned w, int hi, float f) {
-    float out;
-    if (hi) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(f));
-    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w), "v"(f));
-    return out;
-}
-// Softmax over the NT channels of ONE pixel — the low (HF = 0) or the high half of the NT packed words — in place: raw logits
-// -> fp16 weights.  nmx = -max over the channels.  HF is a template parameter: with the asm variants selected by a loop
-// variable the compiler kept the two-trip loop rolled (selects and branches around every asm: 3x the time).
-template <int NT, int HF>
-__device__ __forceinline__ void softmax_half(unsigned (&w)[NT], float nmx) {
-    float v[NT];
-    float den = 0.f;
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        // v - max straight from the packed half (v_fma_mix_f32: half * 1 + float, one rounding = the subtraction's)
-        v[c] = softmax_exp<__half>(half_plus_float(w[c], HF, nmx));
-        den += v[c];
-    }
-    const float inv = reciprocal_refined(den);
-#pragma unroll
-    for (int c = 0; c < NT; ++c) w[c] = HF ? mul_into_half_hi(w[c], v[c], inv) : mul_into_half_lo(w[c], v[c], inv);
-}
-template <int NT>
-__device__ __forceinline__ void softmax_pair(unsigned (&w)[NT]) {
-    unsigned mx2 = 0xfc00fc00u;                           // (-inf, -inf): channel maximum of both pixels at once, on the raw
-#pragma unroll
-    for (int c = 0; c < NT; ++c) mx2 = pk_max_f16(mx2, w[c]);                           // halfs (exact: v_pk_max_f16)
-    const float nlo = -h2f_lo(mx2), nhi = -h2f_hi(mx2);
-    softmax_half<NT, 0>(w, nlo);
-    softmax_half<NT, 1>(w, nhi);
-}
-__device__ __forceinline__ unsigned comp(const uint4& r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); }
-__device__ __forceinline__ void set_comp(uint4& r, int k, unsigned v) {
-    if (k == 0) r.x = v; else if (k == 1) r.y = v; else if (k == 2) r.z = v; else r.w = v;
-}
 
 constexpr int KRES_THREADS = 512;        // default workgroup; 768 threads (3 wavefronts per SIMD, <= 168 VGPRs) serve one-oct strips
 
@@ -951,6 +786,21 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
     a.dbg = rp.debug_stamps;
     const bool clean = kregions_inside_image(g, H, W, T);
     const int score = acc ? 1 : 0;
+    // The dot-product form (cspnk_d2.hip): K = 5, fp16 guidance, fp16 planes, one oct per thread.  One launch for the whole
+    // batch: a workgroup refines its tile of image b, b + images_per_launch, ... back to back.
+    const bool d2_able = K == 5 && g_dtype == CSPN_F16 && state_dtype == CSPN_F16 && g.no == 1;
+    if (rp.step_form == CSPN_STEP_DOT2 && !d2_able)
+        return fail("cspnk_forward_resident: the dot-product step form exists for K = 5 with fp16 guidance, fp16 planes and one oct per thread");
+    if (d2_able && rp.step_form != CSPN_STEP_FMA) {
+        a.ls = cspn_detail::kres_d2_row_stride(g.wo);
+        const size_t ldsb = cspn_detail::kres_d2_lds_bytes(g.dr, a.ls, g.threads);
+        if (ldsb > 160 * 1024) return fail("cspnk_forward_resident: the dot-product form needs %zu bytes of LDS", ldsb);
+        a.b0 = 0;
+        a.nb = g.imgs_per_launch < B ? g.imgs_per_launch : B;
+        a.rounds = ceil_div(B, a.nb);
+        a.last_chunk = 1;
+        return cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, score, clean ? 1 : 0, stream);
+    }
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;

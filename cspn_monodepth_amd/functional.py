@@ -15,7 +15,7 @@ import time
 import torch
 
 from . import _lib
-from ._lib import BLEND_NONE, BLEND_PREMASK, BLEND_SPARSE, CSPN_F16, CSPN_F32, cspn_plan
+from ._lib import BLEND_NONE, BLEND_PREMASK, BLEND_SPARSE, CSPN_F16, CSPN_F32, STEP_AUTO, STEP_DOT2, STEP_FMA, cspn_plan
 
 _DEFAULT_PLANS = {}   # K -> dict, set by set_default_plan (e.g. from a tuning run)
 _EVENT_LOG = None     # when an EventLog: propagate() records (start_event, end_event, n_launches, steps_per_launch)
@@ -750,13 +750,15 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
     return ok
 
 
-def _with_spin_limit(cp):
-    """The cached ctypes plan, or a copy carrying the test hook's spin limit."""
-    if not _RESIDENT_SPIN_LIMIT or cp is None:
+def _with_spin_limit(cp, step_form=0):
+    """The cached ctypes plan, or a copy carrying the test hook's spin limit / a pinned step form."""
+    if (not _RESIDENT_SPIN_LIMIT and not step_form) or cp is None:
         return cp
     c2 = _lib.cspn_resident_plan()
     ctypes.memmove(ctypes.byref(c2), ctypes.byref(cp), ctypes.sizeof(c2))
-    c2.spin_limit = int(_RESIDENT_SPIN_LIMIT)
+    if _RESIDENT_SPIN_LIMIT:
+        c2.spin_limit = int(_RESIDENT_SPIN_LIMIT)
+    c2.step_form = int(step_form)
     return c2
 
 
@@ -872,10 +874,23 @@ def pac_resident_supported(guided, x0, sparse, T, plan=None, target=None):
     return _kres_plan_cached(K, B, H, W, int(T), int(sparse is not None), guided.device, 0, _dt(guided))[0]
 
 
-def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None, threads=0):
+_KRES_STEP_FORM = {"auto": _lib.STEP_AUTO, "fma": _lib.STEP_FMA, "dot2": _lib.STEP_DOT2}[os.environ.get("CSPN_KRES_STEP", "auto")]
+
+
+def set_kres_step_form(form):
+    """Step form of the K x K resident launches (include/cspn_hip.h: cspn_resident_plan.step_form): "auto" (default) takes the
+    dot-product kernel where it exists — K = 5, fp16 guidance, fp16 planes: BASELINE config 3 — "fma" keeps every call on the
+    FMA kernel (the bits of the multi-launch schedule with steps_per_launch = steps_per_phase).  Env: CSPN_KRES_STEP."""
+    global _KRES_STEP_FORM
+    _KRES_STEP_FORM = {"auto": _lib.STEP_AUTO, "fma": _lib.STEP_FMA, "dot2": _lib.STEP_DOT2}[form]
+
+
+def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None, threads=0,
+                         step_form=None):
     """CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54) as weight-resident launches (cspnk_forward_resident):
     guided [B,K*K-1,H,W] fp16, x0 / sparse [B,H,W] fp16 or fp32 -> refined [B,H,W] of that dtype; `score=(target, acc)`
-    fuses the depth metrics into the last launch."""
+    fuses the depth metrics into the last launch.  step_form: None = the module setting (set_kres_step_form), or
+    _lib.STEP_AUTO / STEP_FMA / STEP_DOT2."""
     dev = _require_device(guided, x0, sparse)
     B, C, H, W = guided.shape
     K = int(math.sqrt(C + 1))
@@ -884,14 +899,18 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
     tg, acc = score if score is not None else (None, None)
     blend = BLEND_SPARSE if sparse is not None else BLEND_NONE
     sdt = _dt(x0)
+    form = _KRES_STEP_FORM if step_form is None else int(step_form)
+    if form == _lib.STEP_DOT2 and not (K == 5 and guided.dtype == torch.float16 and x0.dtype == torch.float16):
+        form = _lib.STEP_AUTO                      # a process-wide "dot2" only pins the calls that have the kernel
     if steps_per_phase or spin_limit or debug_stamps is not None or threads:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
         rp.threads = int(threads)
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
+        rp.step_form = form
     else:
-        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, _dt(guided))[1])
+        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, _dt(guided))[1], form)
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspnk_forward_resident(_p(guided), _dt(guided), K, _p(x0), _p(sparse), _p(out), sdt, _p(work), seq, host_err_ptr, B, H, W,

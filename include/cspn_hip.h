@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 6
+#define CSPN_ABI_VERSION 7
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -257,7 +257,11 @@ typedef struct cspn_resident_plan {
     unsigned spin_limit;    /* in: polls before a neighbour wait gives up; 0 = default (~seconds)          */
     unsigned long long* debug_stamps; /* in: developer probe, device buffer [workgroups][16] of 100 MHz wall-clock stamps
                                        * (start, weights derived, then per phase: staged, steps done, exchanged) or NULL */
+    int step_form;          /* cspnk_forward_resident, in: CSPN_STEP_AUTO (0), CSPN_STEP_FMA or CSPN_STEP_DOT2 — see there */
 } cspn_resident_plan;
+#define CSPN_STEP_AUTO 0   /* the dot-product form where it exists (K = 5, fp16 guidance, fp16 planes), else the FMA form  */
+#define CSPN_STEP_FMA 1    /* one v_fma_mix_f32 per tap, fp32 state inside a phase: the bits of the multi-launch schedule   */
+#define CSPN_STEP_DOT2 2   /* v_dot2_f32_f16 on fp16 state pairs, state rounded to half after EVERY step, one launch        */
 /* n_cu <= 0: ask the current device.  Returns 0 (with a message) when no tiling fits. */
 int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
 size_t cspn3_resident_workspace_bytes(int B, int H, int W);
@@ -291,7 +295,13 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
  * cspn_pac_prepare).  Workspace, seq, host_err, plan, co-residency, time-out and completion words: exactly as
  * cspn3_forward_resident (cspnk_resident_workspace_bytes sizes the exchange planes for the state dtype; the plan's
  * quads_per_thread field holds the OCTS per thread; `threads` in: 0 = choose, 512 or 768 = pin the workgroup size).  A batch whose taps do not fit the register files of the chip is
- * chunked into several launches of whole images (config 3: two launches of 12). */
+ * chunked into several launches of whole images (config 3: two launches of 12).
+ * plan->step_form: K = 5 with fp16 guidance and fp16 planes — BASELINE config 3 — has a second kernel (csrc/cspnk_d2.hip,
+ * CSPN_STEP_DOT2, what CSPN_STEP_AUTO picks there): the state is kept as packed fp16 pairs and rounded to half after every
+ * step — as the reference's half tensors are between steps — two taps per v_dot2_f32_f16 with fp32 accumulation, and the
+ * chunks of a batch are refined back to back by ONE launch.  Its results equal the oracle's within the fp16 tolerance of the
+ * configuration but are not the bits of the phase-rounded schedules; CSPN_STEP_FMA keeps those (and is all the other
+ * configurations have). */
 int cspnk_resident_plan(int K, int g_dtype, int B, int H, int W, int T, int blend, int n_cu, cspn_resident_plan* in_out);
 size_t cspnk_resident_workspace_bytes(int B, int H, int W, int state_dtype);
 int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x0, const void* sparse_or_null, void* out,

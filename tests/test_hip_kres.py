@@ -76,7 +76,7 @@ def test_resident_equals_multi_launch_bit_for_bit(K, B, H, W, T, S, sparse, stat
     ref = multi_launch(xt, gt, st, T, S, state)
     with torch.no_grad():
         out = F.pac_forward_resident(gt, xt[:, 0].to(sdt).contiguous(), None if st is None else st[:, 0].to(sdt).contiguous(), T,
-                                     steps_per_phase=S)
+                                     steps_per_phase=S, step_form=F.STEP_FMA)
     torch.cuda.synchronize()
     F.ensure_resident_ok()
     assert out.dtype == ref.dtype == sdt
@@ -101,8 +101,10 @@ def test_768_thread_workgroups_give_the_same_bits(K, B, H, W, T, S, sparse, c_or
     if F.kres_plan(K, B, H, W, T, int(sparse), 0, S, 768) is None:
         pytest.skip("no 768-thread tiling for this shape")
     with torch.no_grad():
-        a = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=768)
-        b_ = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=512)
+        a = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=768,
+                                   step_form=F.STEP_FMA)
+        b_ = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=512,
+                                    step_form=F.STEP_FMA)
     F.ensure_resident_ok()
     assert torch.equal(a, b_)
     assert torch.equal(a, multi_launch(xt, gt, st, T, S, None)[:, 0])
@@ -165,7 +167,18 @@ def test_module_takes_the_resident_path_at_config3(state, c_oracle):
         out = m(xt, gt, sparse_depth=st)
     ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], None if state is None else torch.float32)
     F.ensure_resident_ok()
-    assert torch.equal(out, ref)
+    if state is None:
+        # fp16 planes: the dot-product kernel (csrc/cspnk_d2.hip) — the half-precision recurrence, state rounded after every step —
+        # agrees with the phase-rounded schedule to fp16 rounding of the state, and the FMA form still gives that schedule's bits
+        assert float((out.float() - ref.float()).abs().max()) <= 4e-3 * float(ref.float().abs().max())
+        with torch.no_grad(), resident("on"):
+            F.set_kres_step_form("fma")
+            try:
+                assert torch.equal(m(xt, gt, sparse_depth=st), ref)
+            finally:
+                F.set_kres_step_form("auto")
+    else:
+        assert torch.equal(out, ref)
     f32 = lambda a: a.astype(np.float16).astype(np.float32)               # noqa: E731
     want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)
     scale = float(np.abs(want).max())
@@ -222,9 +235,17 @@ def test_resident_timeout_is_loud(c_oracle):
         with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
             F.ensure_resident_ok()
         assert bool(torch.isnan(out).any())
-        good = F.pac_forward_resident(gt, xt, None, T)
+        good = F.pac_forward_resident(gt, xt, None, T, step_form=F.STEP_FMA)
         ref = multi_launch(xt.unsqueeze(1), gt, None, T, F.kres_plan(K, B, H, W, T)["steps_per_phase"], None)
-    assert torch.equal(good, ref[:, 0])
+        assert torch.equal(good, ref[:, 0])
+        F.ensure_resident_ok()
+        # the dot-product form: same protocol, same loud failure, and a clean launch afterwards
+        out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1, step_form=F.STEP_DOT2)
+        with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
+            F.ensure_resident_ok()
+        assert bool(torch.isnan(out).any())
+        good2 = F.pac_forward_resident(gt, xt, None, T, step_form=F.STEP_DOT2)
+    assert float((good2.float() - ref[:, 0].float()).abs().max()) <= 4e-3 * float(ref.float().abs().max())
     F.ensure_resident_ok()
 
 
@@ -234,7 +255,7 @@ def test_random_shapes_against_the_oracle_and_the_multi_launch_schedule(seed, c_
     the image), step counts incl. odd ones and single-phase runs, phase lengths and workgroup sizes: the resident launch must
     equal the multi-launch schedule of the same phase length bit for bit and stay within the dtype's tolerance of the oracle."""
     rng = np.random.default_rng(4200 + seed)
-    done = 0
+    done = n_dot2 = 0
     for _ in range(40):
         K = int(rng.choice([3, 5]))
         f32 = bool(rng.random() < 0.4)
@@ -257,7 +278,7 @@ def test_random_shapes_against_the_oracle_and_the_multi_launch_schedule(seed, c_
         ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], state)
         with torch.no_grad():
             out = F.pac_forward_resident(gt, xt[:, 0].to(sdt).contiguous(), None if st is None else st[:, 0].to(sdt).contiguous(), T,
-                                         steps_per_phase=S, threads=threads)
+                                         steps_per_phase=S, threads=threads, step_form=F.STEP_FMA)
         case = (K, f32, B, H, W, T, S, threads, sparse, str(state), rp["tiles_x"], rp["tiles_y"], rp["quads_per_thread"])
         assert torch.equal(out, ref[:, 0]), case
         rnd = (lambda a: None if a is None else a.astype(np.float32)) if f32 else (
@@ -266,6 +287,12 @@ def test_random_shapes_against_the_oracle_and_the_multi_launch_schedule(seed, c_
         scale = max(float(np.abs(want).max()), 1e-6)
         tol = 1e-5 if f32 else (8e-3 if sdt == torch.float16 else 4e-3)
         assert float(np.abs(out.float().cpu().numpy() - want).max()) <= tol * scale, case
+        if K == 5 and not f32 and sdt == torch.float16 and rp["quads_per_thread"] == 1:
+            with torch.no_grad():                     # the dot-product form of the same call: oracle tolerance of the fp16 configuration
+                o2 = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T,
+                                            steps_per_phase=S, threads=threads, step_form=F.STEP_DOT2)
+            assert float(np.abs(o2.float().cpu().numpy() - want).max()) <= tol * scale, ("dot2",) + case
+            n_dot2 += 1
         done += 1
     F.ensure_resident_ok()
     assert done >= 10
@@ -344,3 +371,54 @@ def test_k3_fp32_training_forward_publishes_what_the_backward_needs(B, H, W, T, 
         assert float(np.abs(got - want).max()) <= tol * max(1e-12, float(np.abs(want).max()))
     assert np.allclose(grads["on"][0], grads["off"][0], rtol=0, atol=1e-6 * float(np.abs(wx).max()))
     assert np.allclose(grads["on"][1], grads["off"][1], rtol=0, atol=1e-6 * float(np.abs(wg).max()))
+
+
+D2_SHAPES = [(24, 228, 304, 12, 4), (3, 228, 304, 12, 4), (1, 352, 1216, 12, 4), (2, 40, 64, 12, 4), (2, 13, 24, 5, 5), (5, 60, 72, 7, 2),
+             (1, 9, 8, 3, 2), (30, 120, 160, 9, 4), (25, 228, 304, 12, 4), (2, 48, 64, 12, 6)]
+
+
+@pytest.mark.parametrize("B,H,W,T,S", D2_SHAPES, ids=["x".join(map(str, s)) for s in D2_SHAPES])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_dot2_form_against_the_oracle(B, H, W, T, S, sparse, c_oracle):
+    """csrc/cspnk_d2.hip (K = 5, fp16 guidance, fp16 planes — BASELINE config 3's kernel): v_dot2_f32_f16 steps on fp16 state
+    pairs, the state rounded to half after every step, the whole batch in ONE launch (B = 24: two rounds of 12 images, B = 25:
+    a ragged third round).  Directly against the C oracle at every size, full config 3 included (CSPN_ours.py:24-54), within the
+    fp16 tolerance of the configuration; and close to the phase-rounded FMA form."""
+    K = 5
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=160)
+    xt, gt, st = dev(x, torch.float16), dev(gd, torch.float16), dev(s, torch.float16)
+    rp = F.kres_plan(K, B, H, W, T, int(sparse), 0, S)
+    if rp is None or rp["quads_per_thread"] != 1:
+        pytest.skip("no one-oct tiling for this shape / phase length")
+    sp = None if st is None else st[:, 0].contiguous()
+    with torch.no_grad():
+        out = F.pac_forward_resident(gt, xt[:, 0].contiguous(), sp, T, steps_per_phase=S, step_form=F.STEP_DOT2)
+        fma = F.pac_forward_resident(gt, xt[:, 0].contiguous(), sp, T, steps_per_phase=S, step_form=F.STEP_FMA)
+        again = F.pac_forward_resident(gt, xt[:, 0].contiguous(), sp, T, steps_per_phase=S, step_form=F.STEP_DOT2)
+    F.ensure_resident_ok()
+    assert out.dtype == torch.float16 and torch.equal(out, again)
+    f32 = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)      # noqa: E731
+    want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)[:, 0]
+    scale = float(np.abs(want).max())
+    o = out.float().cpu().numpy()
+    assert float(np.abs(o - want).max()) <= 8e-3 * scale and rmse(o, want) <= 3e-3 * scale
+    assert float((out.float() - fma.float()).abs().max()) <= 4e-3 * scale
+
+
+def test_dot2_form_scores_what_it_stores(c_oracle):
+    """Fused metrics of the dot-product form: same refined depth as the plain call, sums equal the separate reduction's."""
+    K, B, H, W, T = 5, 24, 228, 304, 12
+    x, gd, s = inputs(c_oracle, B, H, W, K, True, seed=162)
+    tgt = np.maximum(x + 0.1 * c_oracle.hash_normal(163, 9, x.shape), 0.0).astype(np.float32)
+    tgt[c_oracle.hash_uniform(164, 9, x.shape) < 0.05] = 0.0
+    xt, gt, st, tt = (dev(a, torch.float16) for a in (x, gd, s, tgt))
+    ev = pkg.evaluation
+    with torch.no_grad():
+        acc = ev.new_accumulator(DEV)
+        out = F.pac_forward_resident(gt, xt[:, 0].contiguous(), st[:, 0].contiguous(), T, score=(tt[:, 0].contiguous(), acc),
+                                     step_form=F.STEP_DOT2)
+        ref = F.pac_forward_resident(gt, xt[:, 0].contiguous(), st[:, 0].contiguous(), T, step_form=F.STEP_DOT2)
+        sums, _ = ev.all_gather_metric_sums(acc)
+        want = ev.metric_sums(ref.unsqueeze(1), tt)
+    assert torch.equal(out, ref)
+    assert np.allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
