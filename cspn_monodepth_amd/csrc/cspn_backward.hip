@@ -132,6 +132,42 @@ struct TailArgs {
     int B, H, W, T, C;
 };
 
+// History loads of the tail as RAW bits, converted where they are consumed.  For fp32 planes this is the plain load.  For fp16
+// planes a guarded `ok ? ld(p) : 0` makes an exec-masked block, and the compiler sinks the f16 -> f32 conversion INTO that block
+// (cvt(0) = 0), right behind the load: every block then waits for its own round trip — 10 row quads + the strip-end patches per
+// trip of the stream loop, serialised (cspn_grad_tail<5, __half, ...> ran at 302 us against 127 us for its fp32-history twin,
+// profiles/r04_kernel_stats_train_leg_pac5_state16.csv).  Raw loads from a safe address + a select after the conversion keep
+// every load of a trip in flight together; the empty asm pins the conversion behind the load phase.
+template <typename DT> struct TailRaw;
+template <> struct TailRaw<float> {
+    static constexpr bool RAW = false;        // fp32: the guarded loads themselves (no conversion to sink; 124 VGPRs = 4 waves per SIMD)
+    typedef float4 Q;
+    typedef float S;
+    static __device__ __forceinline__ Q ldq(const float* p) { return ld4(p); }
+    static __device__ __forceinline__ S lds(const float* p) { return *p; }
+    static __device__ __forceinline__ float4 f4(Q q) { return q; }
+    static __device__ __forceinline__ float f1(S s) { return s; }
+    static __device__ __forceinline__ S zero() { return 0.f; }
+};
+template <> struct TailRaw<__half> {
+    static constexpr bool RAW = true;
+    typedef uint2 Q;
+    typedef unsigned S;
+    static __device__ __forceinline__ Q ldq(const __half* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ S lds(const __half* p) { return *reinterpret_cast<const unsigned short*>(p); }
+    static __device__ __forceinline__ float4 f4(Q q) {
+        asm volatile("" : "+v"(q.x), "+v"(q.y));
+        const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&q.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&q.y));
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    static __device__ __forceinline__ float f1(S s) {
+        asm volatile("" : "+v"(s));
+        return __half2float(__ushort_as_half((unsigned short)s));
+    }
+    static __device__ __forceinline__ S zero() { return 0u; }
+};
+
 template <int K, typename DT, typename WT, int VARIANT>
 __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
     constexpr int R = K / 2;
@@ -172,8 +208,10 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
     constexpr int UNR = (K == 3) ? CSPN_TAIL_UNR3 : (K == 5 ? 2 : 1);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t0 = 0; t0 < T; t0 += UNR) {
-        float4 Gq[UNR], midq[UNR][2 * R + 1];
-        float lf[UNR][2 * R + 1][R], rf[UNR][2 * R + 1][R];
+        typedef TailRaw<DT> RW;
+        float4 Gq[UNR];
+        typename RW::Q midq[UNR][2 * R + 1];
+        typename RW::S lf[UNR][2 * R + 1][R], rf[UNR][2 * R + 1][R];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int t = t0 + u;
@@ -186,21 +224,24 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
                 const int row = y + rr - R;
                 const bool rok = tv && row >= 0 && row < H;
                 const DT* rp = d + (size_t)b * HW + (size_t)(rok ? row : 0) * W;
-                midq[u][rr] = rok ? ld4(rp + x) : z4;
+                if constexpr (RW::RAW) midq[u][rr] = RW::ldq(rp + x);     // always a valid address; zeroed at the consumer when !rok
+                else midq[u][rr] = rok ? RW::ldq(rp + x) : z4;
 #pragma unroll
-                for (int c = 0; c < R; ++c) { lf[u][rr][c] = 0.f; rf[u][rr][c] = 0.f; }
+                for (int c = 0; c < R; ++c) { lf[u][rr][c] = RW::zero(); rf[u][rr][c] = RW::zero(); }
                 if (fix_left) {
 #pragma unroll
                     for (int c = 0; c < R; ++c) {
                         const int xx = x + c - R;
-                        lf[u][rr][c] = (rok && xx >= 0) ? ld1(rp + xx) : 0.f;
+                        if constexpr (RW::RAW) lf[u][rr][c] = RW::lds(rp + (xx >= 0 ? xx : 0));
+                        else lf[u][rr][c] = (rok && xx >= 0) ? RW::lds(rp + xx) : RW::zero();
                     }
                 }
                 if (fix_right) {
 #pragma unroll
                     for (int c = 0; c < R; ++c) {
                         const int xx = x + 4 + c;
-                        rf[u][rr][c] = (rok && xx < W) ? ld1(rp + xx) : 0.f;
+                        if constexpr (RW::RAW) rf[u][rr][c] = RW::lds(rp + (xx < W ? xx : W - 1));
+                        else rf[u][rr][c] = (rok && xx < W) ? RW::lds(rp + xx) : RW::zero();
                     }
                 }
             }
@@ -208,18 +249,25 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const float g4[4] = {Gq[u].x, Gq[u].y, Gq[u].z, Gq[u].w};
+            const bool tvu = live && (t0 + u) < T;
+            (void)tvu;
             float win[2 * R + 1][WIN];
 #pragma unroll
             for (int rr = 0; rr < 2 * R + 1; ++rr) {
-                const float m4[4] = {midq[u][rr].x, midq[u][rr].y, midq[u][rr].z, midq[u][rr].w};
+                const int row = y + rr - R;
+                const bool rok = !RW::RAW || (tvu && row >= 0 && row < H);      // fp32: the loads were guarded already
+                const float4 mq = RW::f4(midq[u][rr]);
+                const float m4[4] = {rok ? mq.x : 0.f, rok ? mq.y : 0.f, rok ? mq.z : 0.f, rok ? mq.w : 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
 #pragma unroll
                 for (int c = 0; c < R; ++c) {
                     const float l = dpp_from_prev_lane(m4[4 - R + c]);
                     const float r = dpp_from_next_lane(m4[c]);
-                    win[rr][c] = fix_left ? lf[u][rr][c] : l;
-                    win[rr][R + 4 + c] = fix_right ? rf[u][rr][c] : r;
+                    const float lv = (!RW::RAW || (rok && x + c - R >= 0)) ? RW::f1(lf[u][rr][c]) : 0.f;
+                    const float rv = (!RW::RAW || (rok && x + 4 + c < W)) ? RW::f1(rf[u][rr][c]) : 0.f;
+                    win[rr][c] = fix_left ? lv : l;
+                    win[rr][R + 4 + c] = fix_right ? rv : r;
                 }
             }
 #pragma unroll

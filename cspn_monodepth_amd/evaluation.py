@@ -64,8 +64,8 @@ def metric_sums(pred, target, out=None):
 
 def finalize_metrics(sums):
     """float64[10] sums -> dict of the reference's 10 metrics + 'count'."""
-    # the numbers are about to be used on the host: a weight-resident launch that timed out must raise here, not be
-    # averaged in (a device tensor is waited for first; a host tensor has been through a synchronising copy already)
+    # the numbers are about to be used on the host: a weight-resident launch that timed out is repaired here (or raised, when it
+    # cannot be), not averaged in (a device tensor is waited for first; a host tensor has been through a synchronising copy already)
     if getattr(sums, "is_cuda", False):
         _F.ensure_resident_ok(sums.device)
     else:
@@ -121,17 +121,21 @@ def all_gather_metric_sums(sums, group=None, force_collective=False):
     """All-gather the per-rank sums (world x 10 float64) and add them.  Works with gloo (CPU) and nccl/RCCL.
 
     This is where an evaluation loop hands its numbers on, so it first waits for the weight-resident launches that
-    produced them and raises if one timed out (functional.ensure_resident_ok) — also for the last batch of the loop,
-    which no later launch would check.  Returns (total [10], per_rank [world, 10]), independent tensors."""
+    produced them; one that timed out is re-run on the multi-launch schedule and its metric sums are corrected
+    (functional.ensure_resident_ok) — also for the last batch of the loop, which no later launch would check.  Returns (total [10], per_rank [world, 10]), independent tensors."""
     initialised = dist.is_available() and dist.is_initialized()
     if not initialised or (dist.get_world_size(group) == 1 and not force_collective):
         # one rank: nothing to gather (force_collective: run the collective anyway — the world-size-1 RCCL test and bench.py's
         # forced group).  The copies are enqueued BEHIND the launches first and the wait + check comes after: the same
         # guarantee (nothing is returned from a timed-out launch), without two kernel launches into an idle queue
+        n0 = _F.resident_fallbacks()
         total = sums.sum(0) if sums.dim() == 2 else sums.clone()
         per_rank = total.clone().unsqueeze(0)
         if sums.is_cuda:
             _F.ensure_resident_ok(sums.device)
+            if _F.resident_fallbacks() != n0:          # a timed-out launch was repaired (its sums corrected) after the copies
+                total = sums.sum(0) if sums.dim() == 2 else sums.clone()
+                per_rank = total.clone().unsqueeze(0)
         return total, per_rank
     if sums.is_cuda:
         _F.ensure_resident_ok(sums.device)

@@ -507,8 +507,33 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
 # all T steps, tile borders exchanged between co-resident workgroups.  Its launches must not overlap on a device, so
 # this module serialises them: a lock around (order after the previous resident launch's stream, launch), per device.
 _RESIDENT_MODE = os.environ.get("CSPN_RESIDENT", "auto")      # "auto" | "on" | "off"
-_RES = {}                 # device index -> state dict
-_RES_LOCK = threading.Lock()
+_RES = {}                 # device index -> state dict (each with its OWN launch lock: devices never serialise each other)
+_RES_NEW_LOCK = threading.Lock()      # guards the creation of a device's state only
+# A resident launch whose workgroups were not co-resident (another tenant held CUs past the bounded wait) leaves NaN tiles and
+# an error word.  Inference calls are REPAIRED, not raised: every resident inference launch is journaled (inputs, outputs) and
+# when the error word turns up — at the next launch on the device or wherever the host is about to trust a result
+# (ensure_resident_ok: metric gather / finalise, GraphedForward) — the journaled calls are re-run on the multi-launch
+# schedule into the SAME output tensors (bit-identical by construction) and fused metric sums are corrected.  After
+# _FALLBACK_LIMIT such events mode "auto" switches itself off for the process with one warning.  The reference's runtime
+# surfaces worker errors and never returns partial results (network/libs/base/encoding.py:172-174, :193-194); a co-residency
+# time-out is not an error of the computation, so it is absorbed where that can be done exactly, and raised (as a
+# ResidentLaunchTimeout, after switching "auto" off so that a retry succeeds) where it cannot: training-form launches, whose
+# results were consumed on the GPU before the host could know, and HIP-graph replays.
+_JOURNAL_MAX = 32
+_FALLBACK_LIMIT = 3
+_FALLBACKS = 0
+_FALLBACK_WARNED = False
+
+
+class ResidentLaunchTimeout(RuntimeError):
+    """A weight-resident launch gave up waiting for a neighbouring tile and its result could not be repaired in place (a
+    training step, a HIP-graph replay, or more than _JOURNAL_MAX unchecked launches ago).  Mode "auto" has been switched off
+    for this process: re-running the step takes the multi-launch schedule."""
+
+
+def resident_fallbacks():
+    """Number of times a timed-out resident launch was detected in this process (repaired in place or raised)."""
+    return _FALLBACKS
 # Flag values of one call span seq+1 .. seq+n_phase-1 (a tile that finished phase p publishes seq + p + 1) and the engine
 # refuses more than 255 phases, so a step of 256 keeps the values of consecutive calls on one workspace disjoint
 # (include/cspn_hip.h: "grows by at least 256").
@@ -539,11 +564,89 @@ def resident_plan(B, H, W, T, blend=0, n_cu=0, steps_per_phase=0):
 def _resident_state(dev):
     st = _RES.get(dev.index)
     if st is None:
-        host_err = torch.zeros(4, dtype=torch.int32).pin_memory()
-        st = _RES[dev.index] = dict(seq=_RES_SEQ_STEP, work={}, host_err=host_err, host_err_np=host_err.numpy(),
-                                    host_err_ptr=ctypes.c_void_p(host_err.data_ptr()), dirty=False,
-                                    last_stream=None, n_cu=torch.cuda.get_device_properties(dev).multi_processor_count)
+        with _RES_NEW_LOCK:
+            st = _RES.get(dev.index)
+            if st is None:
+                host_err = torch.zeros(4, dtype=torch.int32).pin_memory()
+                st = _RES[dev.index] = dict(seq=_RES_SEQ_STEP, work={}, host_err=host_err, host_err_np=host_err.numpy(),
+                                            host_err_ptr=ctypes.c_void_p(host_err.data_ptr()), dirty=False, last_stream=None,
+                                            n_cu=torch.cuda.get_device_properties(dev).multi_processor_count,
+                                            lock=threading.RLock(), journal=[], lost=False, last_seq=None, last_reports=False)
     return st
+
+
+def _note_fallback(training=False):
+    """Count a detected time-out; switch mode "auto" off after _FALLBACK_LIMIT of them (at once for a training-form launch: the
+    step that raised is about to be retried)."""
+    global _FALLBACKS, _RESIDENT_MODE, _FALLBACK_WARNED
+    _FALLBACKS += 1
+    if _RESIDENT_MODE == "auto" and (training or _FALLBACKS >= _FALLBACK_LIMIT):
+        _RESIDENT_MODE = "off"
+        if not _FALLBACK_WARNED:
+            _FALLBACK_WARNED = True
+            import warnings
+            warnings.warn("cspn_monodepth_amd: %d weight-resident launch(es) timed out waiting for co-residency (the GPU is shared "
+                          "with another tenant); the resident schedule is switched off for this process — results are unchanged, "
+                          "calls take the multi-launch schedule from now on (functional.set_resident('auto') re-enables it)"
+                          % _FALLBACKS, RuntimeWarning, stacklevel=3)
+
+
+def _recover(dev, st):
+    """The error word of `dev` is set: wait for the journaled launches, clear the word, and re-run the journaled inference calls
+    on the multi-launch schedule into their own output tensors.  Raises ResidentLaunchTimeout when a launch that cannot be
+    repaired is among them (training form, graph replay, or a journal that overflowed since the last clean check)."""
+    with st["lock"]:
+        if st["host_err_np"][0] == 0:
+            return
+        last = st["last_stream"]
+        if last is not None and not torch.cuda.is_current_stream_capturing():
+            last.synchronize()                     # every journaled launch has finished: its outputs may be rewritten
+        st["host_err_np"][0] = 0
+        st["dirty"] = False
+        journal, st["journal"] = st["journal"], []
+        lost, st["lost"] = st["lost"], False
+        st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
+        st["marks"] = []
+        training = any(redo is None for redo in journal)
+        _note_fallback(training=training)
+        if lost or training or not journal:
+            raise ResidentLaunchTimeout(
+                "a weight-resident launch on cuda:%d timed out waiting for a neighbouring tile (the GPU was shared with another "
+                "long-running tenant, so the launch was not co-resident) and its result cannot be repaired in place (%s); the "
+                "output of that call is incomplete (its missing tiles are NaN).  The resident schedule is now off for this "
+                "process (functional.set_resident): re-run the step." % (
+                    dev.index, "a training-form launch" if training else "graph replay / unchecked launches beyond the journal"))
+        with _device_guard(dev):
+            for redo in journal:
+                redo()
+
+
+def _journal_add(dev, st, redo, stream):
+    """Remember how to repair the launch just issued on `stream` (redo = None: it cannot be repaired).  The journal is bounded
+    without ever losing an entry that may still fail: every 16th launch records an event behind itself, and when the journal is
+    full the host waits for the oldest of those marks — 16+ launches back, normally long finished, so the wait returns at once —
+    and drops what lies before it (or repairs everything, if the error word is set by then)."""
+    j = st["journal"]
+    j.append(redo)
+    st["jcount"] = n = st.get("jcount", 0) + 1
+    marks = st.setdefault("marks", [])
+    if n % 16 == 0:
+        pool = st.setdefault("mark_pool", [])
+        ev = pool.pop() if pool else torch.cuda.Event()
+        ev.record(stream)
+        marks.append([len(j), ev])
+    if len(j) >= _JOURNAL_MAX:
+        if st["host_err_np"][0] == 0 and marks:
+            cut, ev = marks.pop(0)
+            ev.synchronize()
+            st["mark_pool"].append(ev)
+            if st["host_err_np"][0] == 0:          # everything up to the mark has finished cleanly
+                del j[:cut]
+                for m in marks:
+                    m[0] -= cut
+                return
+        if st["host_err_np"][0] != 0:
+            _recover(dev, st)
 
 
 def _device_is_oversubscribed():
@@ -609,27 +712,31 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
     return _resident_plan_cached(B, H, W, int(T), int(sparse is not None), guidance.device)[0]
 
 
+def _journal_clear(st):
+    del st["journal"][:]
+    st["lost"] = False
+    st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
+    st["marks"] = []
+
+
 def check_resident_errors(dev=None):
-    """Raise if a resident launch on `dev` (default: every device used so far) gave up waiting for a neighbouring tile —
-    i.e. its workgroups were not co-resident because something else held the GPU for seconds.  Only looks at the error
-    words the launches that have FINISHED wrote: call it after a synchronisation that covers them, or use
-    ensure_resident_ok, which synchronises first.  The result of the failed call is incomplete (its missing tiles are
-    NaN).  Called at the start of every resident launch, by ensure_resident_ok, and at the end of a backward pass."""
+    """If a resident launch on `dev` (default: every device used so far) gave up waiting for a neighbouring tile — its workgroups
+    were not co-resident because something else held the GPU — repair the journaled inference calls in place (see the note at
+    the top of this section), or raise ResidentLaunchTimeout when that is not possible.  Only sees the error words of launches
+    that have FINISHED: call it after a synchronisation that covers them, or use ensure_resident_ok, which synchronises first.
+    Called at the start of every resident launch, by ensure_resident_ok, and at the end of a backward pass."""
     for idx, st in list(_RES.items()):
         if (dev is None or dev.index == idx) and st["host_err_np"][0] != 0:
-            st["host_err_np"][0] = 0
-            st["dirty"] = False
-            raise RuntimeError("cspn3_forward_resident on cuda:%d timed out waiting for a neighbouring tile (the GPU was "
-                               "shared with another long-running tenant, so the launch was not co-resident); the output of "
-                               "that call is incomplete.  Use cspn_monodepth_amd.functional.set_resident('off') or "
-                               "CSPN_RESIDENT=off when the device is shared." % idx)
+            _recover(torch.device("cuda", idx), st)
 
 
 def ensure_resident_ok(dev=None):
-    """Wait for the resident launches issued so far on `dev` (default: every device) and raise if one of them timed out.
-    This is what every consumer of a result on the host calls before it trusts the numbers — evaluation.
-    all_gather_metric_sums / finalize_metrics do; a training step gets the equivalent at the end of its backward pass
-    (CSPN3Function.backward).  Costs nothing when no resident launch is pending (no synchronisation then)."""
+    """Wait for the resident launches issued so far on `dev` (default: every device) and make their results trustworthy: a
+    launch that timed out is re-run on the multi-launch schedule (same bits, fused metric sums corrected), or raised as a
+    ResidentLaunchTimeout when it cannot be (training form, graph replay).  This is what every consumer of a result on the
+    host calls before it trusts the numbers — evaluation.all_gather_metric_sums / finalize_metrics do; a training step gets
+    the equivalent at the end of its backward pass (CSPN3Function.backward).  Costs nothing when no resident launch is pending
+    (no synchronisation then)."""
     for idx, st in list(_RES.items()):
         if dev is not None and dev.index != idx:
             continue
@@ -638,7 +745,12 @@ def ensure_resident_ok(dev=None):
             if last is not None and not torch.cuda.is_current_stream_capturing():
                 last.synchronize()
             st["dirty"] = False
-    check_resident_errors(dev)
+        if st["host_err_np"][0] != 0:
+            _recover(torch.device("cuda", idx), st)
+        elif st["journal"]:
+            with st["lock"]:
+                if st["host_err_np"][0] == 0 and not st["dirty"]:      # everything issued so far has finished cleanly
+                    _journal_clear(st)
 
 
 def mark_resident_pending(t=None):
@@ -649,6 +761,8 @@ def mark_resident_pending(t=None):
     if st is not None:
         st["dirty"] = True
         st["last_stream"] = torch.cuda.current_stream(dev)
+        st["lost"] = True                 # a replayed launch cannot be re-run from here: a time-out inside it raises
+        st["last_seq"] = None             # (and a pending end-of-backward checkpoint must not poll for a captured seq)
 
 
 class _ResidentCheckpoint(object):
@@ -673,25 +787,35 @@ class _ResidentCheckpoint(object):
             spins = 0
             while True:
                 spins += 1
-                if spins % 4096 == 0:
-                    time.sleep(0)                       # long waits (a stalled device) yield the interpreter to other threads
                 if words[0] != 0:
                     break
                 if ((int(words[1]) - self.seq) & 0xffffffff) < 0x80000000:      # done word has reached (or passed) this call
                     break
-                if t_end is None:
-                    t_end = time.perf_counter() + budget_s
-                elif time.perf_counter() > t_end:        # a graph replay or a sequence wrap in between: wait the plain way
-                    if self.stream is not None:
+                if st["last_seq"] is None:               # a graph replay or a sequence wrap came in between: the completion
+                    if self.stream is not None:          # word no longer counts this call's way — wait the plain way, at once
                         self.stream.synchronize()
                     break
+                if spins > 2048:                         # past ~0.2 ms this is a stalled device, not the tail of a step: back
+                    time.sleep(5e-5)                     # off and let other threads have the interpreter
+                    if t_end is None:
+                        t_end = time.perf_counter() + budget_s
+                    elif time.perf_counter() > t_end:
+                        if self.stream is not None:
+                            self.stream.synchronize()
+                        break
+            if words[0] == 0 and st["last_reports"] and st["last_seq"] == self.seq:
+                with st["lock"]:                         # the newest launch has finished cleanly: nothing is left to repair
+                    if words[0] == 0 and st["last_seq"] == self.seq:
+                        _journal_clear(st)
         check_resident_errors(self.dev)
 
 
-def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None, reports_done=False):
-    """The host protocol of every resident launch on `dev`: one at a time per device (lock; a launch from another stream
-    first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence number,
-    the sticky error word checked before the call.  `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call.
+def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None, reports_done=False, redo=None):
+    """The host protocol of every resident launch on `dev`: one at a time per device (the device's own lock; a launch from
+    another stream first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence
+    number, the error word looked at before the call (a time-out of an earlier launch is repaired or raised there: _recover).
+    `launch(work, seq, host_err_ptr, stream_ptr)` makes the C call; `redo()` re-runs the call on the multi-launch schedule into
+    the same outputs (None: the launch cannot be repaired — training forms).
 
     Under HIP-graph capture a replay cannot bring a new sequence number, so the capture records a memset of the
     workspace's control words (status + tile flags, a few KB behind the two exchange planes: include/cspn_hip.h) in front
@@ -713,10 +837,10 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
         with _device_guard(dev):
             cur = torch.cuda.current_stream(dev)
             return launch(work, _RES_SEQ_STEP, st["host_err_ptr"], ctypes.c_void_p(cur.cuda_stream))
-    with _RES_LOCK:
-        st = _resident_state(dev)
+    st = _resident_state(dev)
+    with st["lock"]:
         if st["host_err_np"][0] != 0:
-            check_resident_errors(dev)                  # raises
+            _recover(dev, st)                           # repairs the journaled calls, or raises
         key = (B, H, W, ws_kind, state_bytes)
         work = st["work"].get(key)
         if work is None:
@@ -728,18 +852,15 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
             last = st["last_stream"]
             if last is not None and last != cur:
                 cur.wait_stream(last)                   # resident launches never overlap on a device
-            st["last_stream"] = cur
-            st["dirty"] = True
             if st["seq"] > _RES_SEQ_MAX:                # flag values wrap: start over on clean workspaces (zeroed on `cur`,
                 for w_ in st["work"].values():          # behind every earlier resident launch)
                     w_.zero_()
                 st["seq"] = _RES_SEQ_STEP
                 cur.synchronize()                       # (once per ~8 M calls) the completion word starts over as well
                 st["host_err_np"][1] = 0
+                st["last_seq"] = None                   # ... and a pending checkpoint of the old numbering waits the plain way
             seq = st["seq"]
             st["seq"] = seq + _RES_SEQ_STEP
-            if reports_done:                            # training-form launches store `seq` to the completion word
-                st["last_seq"] = seq
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
@@ -747,6 +868,13 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
             if log is not None:
                 ev1.record(cur)
                 log.append((ev0, ev1, 1, T))
+            if ok:                                      # (a call that failed at submit has enqueued nothing)
+                st["last_stream"] = cur
+                st["dirty"] = True
+                st["last_reports"] = bool(reports_done)
+                if reports_done:                        # training-form launches store `seq` to the completion word
+                    st["last_seq"] = seq
+                _journal_add(dev, st, redo, cur)
     return ok
 
 
@@ -760,6 +888,16 @@ def _with_spin_limit(cp, step_form=0):
         c2.spin_limit = int(_RESIDENT_SPIN_LIMIT)
     c2.step_form = int(step_form)
     return c2
+
+
+def _unscore_failed_launch(out, tg, acc):
+    """A scored resident launch that timed out has added the sums of the tiles that DID finish to `acc` (the tiles that gave up
+    return before their scoring; their part of `out` is NaN).  Take those sums out again, so that the re-run can score the whole
+    batch exactly once: they are the metric sums over the finite part of the failed output."""
+    from . import evaluation
+    bad = torch.isnan(out)
+    part = evaluation.metric_sums(torch.where(bad, torch.ones_like(out), out), torch.where(bad, torch.zeros_like(tg), tg))
+    acc[0] -= part
 
 
 def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
@@ -812,7 +950,18 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
                                         int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                         None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history))
+    redo = None
+    if not keep_history:
+        def redo():            # the same call on the multi-launch schedule, into the same tensors (bit-identical: §4.1b)
+            from . import evaluation
+            if score is not None:
+                _unscore_failed_launch(out, tg, acc)
+            res, _ = propagate_from_guidance(guidance, d0, sparse, T, blend, valid_w=valid_w)
+            out.copy_(res)
+            if score is not None:
+                evaluation.metric_sums(out, tg, out=acc)
+
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo)
     _lib.check(ok, "cspn3_forward_resident")
     if keep_history:
         return hist[int(T) - 1], hist, w8, S_out
@@ -917,8 +1066,18 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
                                         int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                         None if rp is None else ctypes.byref(rp), stream_ptr)
 
+    def redo():                # prepare + multi-launch propagation into the same tensor (fp32: the same bits; fp16 planes: the
+        from . import evaluation       # phase-rounded schedule, within fp16 rounding of the state of the dot-product form)
+        if score is not None:
+            _unscore_failed_launch(out, tg, acc)
+        wk, _ = pac_prepare(guided)
+        res, _ = propagate(wk, x0, sparse, K, int(T), blend, plan=dtype_default_plan(K, wk.dtype, None))
+        out.copy_(res)
+        if score is not None:
+            evaluation.metric_sums(out, tg, out=acc)
+
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
-                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt))
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), redo=redo)
     _lib.check(ok, "cspnk_forward_resident")
     return out
 
@@ -1031,7 +1190,8 @@ def _check_resident_at_end_of_backward(dev):
     if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing() or os.environ.get("CSPN_BWD_CHECK") == "off":
         return                     # (CSPN_BWD_CHECK=off: A/B switch for measurements; the next resident launch still raises)
     cp = _ResidentCheckpoint(dev)
-    st["dirty"] = False            # everything issued so far is covered by the checkpoint
+    if st.get("last_reports"):     # the newest launch is the one the checkpoint waits for: everything issued so far is covered
+        st["dirty"] = False        # (a later inference launch does not report completion: the next ensure_resident_ok still waits)
     try:
         torch.autograd.Variable._execution_engine.queue_callback(cp.wait_and_check)
     except RuntimeError:           # not inside an engine-driven backward (a direct call of .backward on the ctx): check now

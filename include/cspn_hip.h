@@ -15,8 +15,16 @@
  *   - optional tensors are passed as NULL (lib_cffi.cpp:62-63 maps empty tensors to NULL);
  *   - the caller owns every buffer (including workspace); the library never allocates,
  *     frees or retains device pointers, enqueues on the given stream and does not synchronise;
- *   - re-entrant: no global mutable state; the caller selects the device (hipSetDevice)
- *     before the call, as `with torch.cuda.device(...)` does at encoding.py:168.
+ *   - no global mutable state in the library (beyond the thread-local error string and caches of immutable device
+ *     properties); the caller selects the device (hipSetDevice) before the call, as `with torch.cuda.device(...)` does at
+ *     encoding.py:168.  The streaming entry points are re-entrant: any number of host threads, devices and streams at
+ *     once.  The WEIGHT-RESIDENT entry points (cspn3_forward_resident, cspn3_transposed_resident, cspnk_forward_resident*)
+ *     are thread-safe but put a protocol on the caller, stated with each of them: one such launch at a time per DEVICE
+ *     (their workgroups wait for each other), a zero-initialised workspace that only these entries ever touch, a `seq`
+ *     that grows by at least 256 per call on a workspace, two pinned host words for the time-out / completion reports.
+ *     cspn_monodepth_amd/functional.py implements that protocol (a lock per device, a journal that repairs a timed-out
+ *     inference call on the streaming schedule); a host that cannot keep to it uses the streaming entries, which give
+ *     the same bits.
  *
  * Scope of the 3x3 entries: the reference's CSPN_new.AffinityPropagate is only meaningful for prop_kernel = 3 (with 5 its
  * ones-kernel becomes 1x2x2 and the output silently shrinks to (H-1)x(W-1), CSPN_new.py:122); the host module raises
@@ -232,7 +240,11 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * device (cspn_monodepth_amd/functional.py chains them with events).  The neighbour wait is bounded (seconds): on
  * time-out the launch stores 1 to status word 1 of the workspace (and to host_err[0], if given),
  * drains, and leaves `out` incomplete — the tiles that gave up are filled with NaN (in `out`, or in the last history
- * plane) — and the caller must check the word before trusting the result (functional.ensure_resident_ok).
+ * plane) — and the caller must look at the word before trusting the result and re-run the call on the streaming entries
+ * (cspn3_propagate_from_guidance: the same bits) when it is set.  cspn_monodepth_amd/functional.py does that for its callers:
+ * inference calls are journaled and repaired in place at the next launch or host-side consumer (ensure_resident_ok),
+ * training-form calls raise ResidentLaunchTimeout before `.backward()` returns, and after three time-outs the resident
+ * schedule switches itself off for the process.
  *
  * host_err_or_null: TWO host-mapped 32-bit words (pinned host memory the device can write): [0] receives 1 on a time-out;
  * [1] receives `seq` when the last launch of a TRAINING-form call (history != NULL) or of cspn3_transposed_resident has

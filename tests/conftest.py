@@ -18,6 +18,21 @@ def pytest_configure(config):
     _lib.build()
 
 
+def pytest_collection_modifyitems(config, items):
+    # a box without a ROCm GPU reports the `gpu` tests as skipped instead of failing them one by one
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:       # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a ROCm GPU (MI355X): run with -m gpu on the GPU box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def golden_names(prefix):
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
 
@@ -51,3 +66,31 @@ def c_oracle():
     from oracle import c_oracle as c
     c.build()
     return c
+
+
+@pytest.fixture(autouse=True)
+def _fresh_resident_fallback_state():
+    """Time-out tests count fallbacks and may switch mode "auto" off for the process (functional._note_fallback): every test
+    starts from a clean count and leaves the mode as it found it."""
+    from cspn_monodepth_amd import functional as F
+    mode = F._RESIDENT_MODE
+    F._FALLBACKS, F._FALLBACK_WARNED = 0, False
+    yield
+    F._RESIDENT_MODE = mode
+    F._FALLBACKS, F._FALLBACK_WARNED = 0, False
+
+
+def occupy_lib():
+    """tests/support/libcspn_occupy.so (a co-tenant kernel for the contention tests), built on demand with hipcc."""
+    import ctypes
+    import shutil
+    import subprocess
+    src = os.path.join(ROOT, "tests", "support", "occupy.hip")
+    so = os.path.join(ROOT, "tests", "support", "libcspn_occupy.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-Wno-unused-value", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+    lib.occupy.restype = ctypes.c_int
+    return lib

@@ -24,3 +24,39 @@ def test_use_tuned_conv_db_copies_per_rank_and_respects_the_environment(monkeypa
     assert conv_tuning.use_tuned_conv_db(rank=1) is None and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
     d1 = conv_tuning.use_tuned_conv_db(rank=1, force=True)
     assert d1 and d1 != d0 and os.environ["MIOPEN_USER_DB_PATH"] == d1
+
+
+def test_database_copy_is_private_and_never_follows_planted_links(monkeypatch, tmp_path):
+    """the per-rank copy must not live under a predictable name in the world-writable temp dir, must refuse
+    a directory it does not own privately, must not follow a symlink planted where a file goes, and must keep what MIOpen
+    appended on an earlier run."""
+    import stat
+    import pytest
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/42")
+    d = conv_tuning.use_tuned_conv_db(rank=3)
+    assert d.startswith(str(tmp_path / "cache")) and "job_42" in d and d.endswith("rank3")
+    assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    f = sorted(os.listdir(d))[0]
+    with open(os.path.join(d, f), "a") as fh:
+        fh.write("learned=1\n")
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    assert conv_tuning.use_tuned_conv_db(rank=3) == d                 # same job + rank: the same directory ...
+    assert open(os.path.join(d, f)).read().endswith("learned=1\n")   # ... and the appended line is still there
+    # a symlink planted where a database file goes is left alone, its target untouched
+    victim = tmp_path / "victim"
+    victim.write_text("precious")
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    d2 = os.path.join(os.path.dirname(d), "miopen_db_job_42_rank4")
+    os.mkdir(d2, 0o700)
+    os.symlink(str(victim), os.path.join(d2, f))
+    conv_tuning.use_tuned_conv_db(rank=4)
+    assert victim.read_text() == "precious"
+    # a directory other users can write to is refused
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    d3 = os.path.join(os.path.dirname(d), "miopen_db_job_42_rank5")
+    os.mkdir(d3, 0o777)
+    os.chmod(d3, 0o777)
+    with pytest.raises(RuntimeError, match="not a private directory"):
+        conv_tuning.use_tuned_conv_db(rank=5)

@@ -226,26 +226,27 @@ def test_reference_goldens_through_the_resident_launch(name):
     F.ensure_resident_ok()
 
 
-def test_resident_timeout_is_loud(c_oracle):
+def test_resident_timeout_is_repaired_in_place(c_oracle):
+    """A K x K resident launch that gives up (spin limit 1) poisons its tiles; where the host next trusts a result
+    (ensure_resident_ok) the call is re-run on the multi-launch schedule into the same tensor — no raise."""
     K, B, H, W, T = 5, 12, 228, 304, 12
     x, gd, _ = inputs(c_oracle, B, H, W, K, False, seed=65)
     xt, gt = dev(x, torch.float16)[:, 0].contiguous(), dev(gd, torch.float16)
     with torch.no_grad():
-        out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1)
-        with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
-            F.ensure_resident_ok()
-        assert bool(torch.isnan(out).any())
-        good = F.pac_forward_resident(gt, xt, None, T, step_form=F.STEP_FMA)
         ref = multi_launch(xt.unsqueeze(1), gt, None, T, F.kres_plan(K, B, H, W, T)["steps_per_phase"], None)
-        assert torch.equal(good, ref[:, 0])
-        F.ensure_resident_ok()
-        # the dot-product form: same protocol, same loud failure, and a clean launch afterwards
-        out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1, step_form=F.STEP_DOT2)
-        with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
+        for form in (F.STEP_FMA, F.STEP_DOT2):
+            out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1, step_form=form)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(out).any())
+            n = F.resident_fallbacks()
             F.ensure_resident_ok()
-        assert bool(torch.isnan(out).any())
-        good2 = F.pac_forward_resident(gt, xt, None, T, step_form=F.STEP_DOT2)
-    assert float((good2.float() - ref[:, 0].float()).abs().max()) <= 4e-3 * float(ref.float().abs().max())
+            assert F.resident_fallbacks() == n + 1
+            assert torch.equal(out, ref[:, 0])                         # the multi-launch schedule's bits (S = 4: the default plan)
+            good = F.pac_forward_resident(gt, xt, None, T, step_form=form)
+            if form == F.STEP_FMA:
+                assert torch.equal(good, ref[:, 0])
+            else:
+                assert float((good.float() - ref[:, 0].float()).abs().max()) <= 4e-3 * float(ref.float().abs().max())
     F.ensure_resident_ok()
 
 

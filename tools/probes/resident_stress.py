@@ -7,6 +7,7 @@ import cspn_monodepth_amd as pkg
 from cspn_monodepth_amd import functional as F
 dev = "cuda:0"
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+sparse = len(sys.argv) > 2 and sys.argv[2] == "sparse"      # blended instances (a 0.7 % sparse depth)
 torch.manual_seed(0)
 bad_total = 0
 for (B, H, W) in ((24, 228, 304), (3, 228, 304), (1, 352, 1216), (8, 352, 1216)):
@@ -14,10 +15,10 @@ for (B, H, W) in ((24, 228, 304), (3, 228, 304), (1, 352, 1216), (8, 352, 1216))
     for k in range(3):                      # alternate inputs: stale exchange data of the previous call must show up
         g = torch.randn(B, 12, H, W, device=dev)
         d = torch.rand(B, 1, H, W, device=dev) * 10
-        sets.append((g, d))
+        sets.append((g, d, (d * (torch.rand_like(d) < 0.007)) if sparse else None))
     m = pkg.CSPN_new.AffinityPropagate(24, 3)
     with torch.no_grad():
-        F.set_resident("off"); refs = [m(g, d) for g, d in sets]
+        F.set_resident("off"); refs = [m(g, d, sp) for g, d, sp in sets]
         F.set_resident("on")
         bad = 0
         n = iters if B * H * W < 2e6 else iters // 4

@@ -21,6 +21,8 @@ ap.add_argument("--T", type=int, default=0, help="propagation steps (default: 24
 ap.add_argument("--K", type=int, default=3)
 ap.add_argument("--dtype", choices=("f32", "f16"), default="f32")
 ap.add_argument("--module", choices=("auto", "new", "ours"), default="auto", help="K = 3: CSPN_new (default) or CSPN_ours (softmax taps)")
+ap.add_argument("--state", choices=("reference", "input"), default="reference",
+                help="CSPN_ours with half inputs: fp32 state as the reference promotes it (default) or the input dtype (what bench.py --workload pac5 runs)")
 a = ap.parse_args()
 dev = "cuda:0"
 dt = torch.float16 if a.dtype == "f16" else torch.float32
@@ -35,7 +37,7 @@ if not ours:
     m = pkg.CSPN_new.AffinityPropagate(T, 3)
     run = lambda: m(g, d, s)                   # noqa: E731
 else:
-    m = pkg.CSPN_ours.AffinityPropagate(T)
+    m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype="reference" if a.state == "reference" else None)
     run = lambda: m(d, g, s)                   # noqa: E731
 for _ in range(a.iters):
     g.grad = None
