@@ -23,7 +23,7 @@ int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, vo
 // cspnk_d2.hip: the K = 5 fp16 form with the state packed as fp16 pairs in LDS and v_dot2_f32_f16 steps (launched by cspnk_forward_resident)
 int kres_d2_row_stride(int wo);
 size_t kres_d2_lds_bytes(int dr, int ls, int threads);
-int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int score, int clean, void* stream);
+int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, void* stream);   // mode 0 plain, 1 scored, 2 history
 }  // namespace cspn_detail
 
 namespace {

@@ -65,6 +65,13 @@ __device__ __forceinline__ float half_scaled(unsigned w, float scale, float add)
 constexpr int D2_LO[12] = {0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 4, 18};
 constexpr int D2_HI[12] = {1, 3, 6, 8, 11, 13, 15, 17, 20, 22, 9, 23};
 
+constexpr int d2_slot(int c) {            // the tap-pair register that holds channel c ...
+    for (int s = 0; s < 12; ++s)
+        if (D2_LO[s] == c || D2_HI[s] == c) return s;
+    return -1;
+}
+constexpr int d2_half(int c) { return D2_HI[d2_slot(c)] == c ? 1 : 0; }      // ... and the half of it
+
 // softmax over the 24 channels of ONE pixel (half HF of the 24 packed words) -> its 12 tap-pair registers.  nmx = -max * log2(e).
 template <int HF>
 __device__ __forceinline__ void softmax_to_pairs(const unsigned (&w)[24], float nmx, unsigned (&out)[12]) {
@@ -83,9 +90,13 @@ __device__ __forceinline__ void softmax_to_pairs(const unsigned (&w)[24], float 
 
 constexpr int D2_R = 2, D2_NT = 24;
 
-template <int BLEND, int SCORE, int CLEAN, int NTH>
+// MODE 0: inference; 1: inference + fused depth metrics; 2: the training forward — every step's state goes to its fp16 history
+// plane and the softmax taps are published once as the fp16 tap volume (pairs (2i, 2i+1) interleaved per quad: cspn_common.hpp
+// Taps<__half>) that cspn_transpose_kernel / cspn_grad_tail<5, __half, __half> stream in the backward.
+template <int BLEND, int MODE, int CLEAN, int NTH>
 __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
     constexpr int R = D2_R, NT = D2_NT;
+    constexpr bool SCORE = MODE == 1, HIST = MODE == 2;
     using IO = StateIO<__half>;
     using Oct = IO::Oct;
     using Pair = IO::Pair;
@@ -104,6 +115,17 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
     const unsigned HW = (unsigned)(H * W);
     const size_t plane = (size_t)a.B * HW;
     int n_stamp = 0;
+    // Training form: every workgroup counts itself out when it has finished all its rounds (or given up); the last one re-arms the
+    // counter and stores `seq` to the second host word — the completion report the end-of-backward check polls (cspn_resident.hip).
+    auto count_out = [&]() {
+        if (HIST && tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == gridDim.x) {
+                __hip_atomic_store(a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.host_err) __hip_atomic_store(a.host_err + 1, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
 
     // ---- ownership: thread (sy, sx) owns oct sx of region row sy (tile + halo), one oct per thread ---------------------
     const int wo = a.wo, wr = a.wr;
@@ -228,6 +250,27 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
             softmax_to_pairs<0>(w, -h2f_lo(mx2) * L2E, wq[2 * q]);
             softmax_to_pairs<1>(w, -h2f_hi(mx2) * L2E, wq[2 * q + 1]);
         }
+        if (HIST && interior) {
+            // publish the taps (before the blend is folded in): pair i = taps (2i, 2i+1), one 16-byte store per pair and quad —
+            // dwords (tap 2i: px 0,1 | px 2,3), (tap 2i+1: px 0,1 | px 2,3) — rebuilt from the tap-pair registers by byte permutes
+            __half* wkb = static_cast<__half*>(a.wk_out) + (size_t)b * Taps<__half>::image_elems(NT, HW);
+            const unsigned hw4 = (unsigned)Taps<__half>::hw4(HW);
+            const unsigned qd = off_r >> 2;                  // (the per-round opaque copy: see the guidance loads)
+#pragma unroll
+            for (int i = 0; i < NT / 2; ++i) {
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    unsigned dw[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = 2 * i + (k >> 1), e = 4 * hq + 2 * (k & 1);
+                        const unsigned lo = wq[e][d2_slot(c)], hi = wq[e + 1][d2_slot(c)];
+                        dw[k] = d2_half(c) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                    }
+                    st16(atb(wkb, ((unsigned)i * 2u * hw4 + (qd + (unsigned)hq) * 8u) * 2u), make_uint4(dw[0], dw[1], dw[2], dw[3]));
+                }
+            }
+        }
         // sparse blend (CSPN_ours.py:51-53): (1-m) u + m x0, m = sign(sparse); 1-m in {0, 1, 2} is folded into the taps (exact in
         // fp16), the steps start their sums from md = m x0
         float md[BLEND ? 8 : 1];
@@ -247,7 +290,8 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
         stamp();                                              // weights derived
 
         // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes --------------------
-        __half* __restrict__ outb = kuniform_ptr(static_cast<__half*>(a.out) + (size_t)b * HW);
+        __half* __restrict__ outb = HIST ? nullptr : kuniform_ptr(static_cast<__half*>(a.out) + (size_t)b * HW);
+        __half* hist_step = HIST ? kuniform_ptr(static_cast<__half*>(a.hist) + (size_t)b * HW) : nullptr;   // plane of the step being computed
         const int tile_global = b * tiles_per_img + trem;
         uint4 fin = make_uint4(0u, 0u, 0u, 0u);               // the final step's packed result (scored after the loop)
         bool aborted = false;
@@ -367,13 +411,15 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
                 uint4 o = make_uint4(cvt_pk_f16(acc[0], acc[1]), cvt_pk_f16(acc[2], acc[3]), cvt_pk_f16(acc[4], acc[5]), cvt_pk_f16(acc[6], acc[7]));
                 if (!CLEAN) { if (!in_img) o = make_uint4(0u, 0u, 0u, 0u); }        // zero padding stays exactly zero
                 if (kind == 1) { if (interior) st16_dev(xout, off_own * 2u, o); }
-                else if (kind == 2) { if (interior) st16(atb(outb, off_own * 2u), o); fin = o; }
+                else if (kind == 2 && !HIST) { if (interior) st16(atb(outb, off_own * 2u), o); fin = o; }
+                if (HIST && interior) st16(atb(hist_step, off_own * 2u), o);
                 if (kind != 2 && active) *reinterpret_cast<uint4*>(wrb + (sy + R) * ls + 4 * (sx + 1)) = o;
             };
             const bool any = __ballot(active) != 0ull;       // wavefronts without a single owned row only keep the barriers company
             for (int s = 0; s < steps; ++s) {
                 const int kind = (s == steps - 1) ? (last_phase ? 2 : 1) : 0;
                 if (any) step(kind, ldsu + (s & 1) * pp, ldsu + ((s + 1) & 1) * pp);
+                if (HIST) hist_step += plane;
                 if (kind == 0) __syncthreads();
             }
             stamp();                                          // steps of the phase done
@@ -415,10 +461,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
             }
             // poison what this workgroup will never produce — this round's tile and the tiles of its remaining rounds — with NaN
             const uint4 qn = make_uint4(0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u);
+            __half* const pz = HIST ? static_cast<__half*>(a.hist) + (size_t)(a.T - 1) * plane : static_cast<__half*>(a.out);   // x_T
             for (int r2 = round; r2 < a.rounds; ++r2) {
                 const int b2 = a.b0 + r2 * a.nb + bl;
-                if (b2 < a.B && interior) st16(atb(static_cast<__half*>(a.out) + (size_t)b2 * HW, off_own * 2u), qn);
+                if (b2 < a.B && interior) st16(atb(pz + (size_t)b2 * HW, off_own * 2u), qn);
             }
+            count_out();
             return;
         }
         if (SCORE) {
@@ -449,11 +497,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
         }
         stamp();                                              // epilogue done
     }
+    count_out();
 }
 
-template <int BLEND, int SCORE, int CLEAN, int NTH>
+template <int BLEND, int MODE, int CLEAN, int NTH>
 int d2_launch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspnk_d2<BLEND, SCORE, CLEAN, NTH>;
+    constexpr auto kern = cspnk_d2<BLEND, MODE, CLEAN, NTH>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -466,11 +515,11 @@ int d2_launch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st
     return 1;
 }
 template <int NTH>
-int d2_launch_nth(const KResArgs& a, int grid, size_t lds, int blend, int score, int clean, hipStream_t st) {
-#define D2_CASE(BL, SC, CL) \
-    if (blend == BL && score == SC && clean == CL) return d2_launch_inst<BL, SC, CL, NTH>(a, grid, lds, st)
-    D2_CASE(0, 0, 0); D2_CASE(0, 0, 1); D2_CASE(0, 1, 0); D2_CASE(0, 1, 1);
-    D2_CASE(1, 0, 0); D2_CASE(1, 0, 1); D2_CASE(1, 1, 0); D2_CASE(1, 1, 1);
+int d2_launch_nth(const KResArgs& a, int grid, size_t lds, int blend, int mode, int clean, hipStream_t st) {
+#define D2_CASE(BL, MD, CL) \
+    if (blend == BL && mode == MD && clean == CL) return d2_launch_inst<BL, MD, CL, NTH>(a, grid, lds, st)
+    D2_CASE(0, 0, 0); D2_CASE(0, 0, 1); D2_CASE(0, 1, 0); D2_CASE(0, 1, 1); D2_CASE(0, 2, 0); D2_CASE(0, 2, 1);
+    D2_CASE(1, 0, 0); D2_CASE(1, 0, 1); D2_CASE(1, 1, 0); D2_CASE(1, 1, 1); D2_CASE(1, 2, 0); D2_CASE(1, 2, 1);
 #undef D2_CASE
     return fail("cspnk_forward_resident (dot2 form): internal dispatch");
 }
@@ -495,11 +544,11 @@ size_t kres_d2_lds_bytes(int dr, int ls, int threads) {
     return ((size_t)2 * dr * ls + (size_t)(threads / 64) * 10 + 16) * sizeof(unsigned);
 }
 
-int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int score, int clean, void* stream) {
+int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, void* stream) {
     const KResArgs& a = *static_cast<const KResArgs*>(kres_args);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (threads == 768) return d2_launch_nth<768>(a, grid, lds_bytes, blend, score, clean, st);
-    if (threads == 512) return d2_launch_nth<512>(a, grid, lds_bytes, blend, score, clean, st);
+    if (threads == 768) return d2_launch_nth<768>(a, grid, lds_bytes, blend, mode, clean, st);
+    if (threads == 512) return d2_launch_nth<512>(a, grid, lds_bytes, blend, mode, clean, st);
     return fail("cspnk_forward_resident (dot2 form): %d threads (512 or 768)", threads);
 }
 

@@ -23,6 +23,8 @@ struct KResArgs {
     int tw, th, tiles_x, tiles_y;
     int wo, wr, hxw, hyw, dr, ls;
     int b0, nb, last_chunk;
+    void* hist;              // cspnk_d2 training form: [T][B,H,W] ST receives x_1 .. x_T (`out` unused)
+    void* wk_out;            // cspnk_d2 training form: the softmax taps as the fp16 tap volume the backward streams (Taps<__half> layout)
     int rounds;              // cspnk_d2: a workgroup refines its tile of images b0 + r * nb + (tile / tiles_per_img), r = 0 .. rounds-1, back to back
     unsigned spin_limit;
     unsigned long long* dbg;  // developer probe: [grid][16] wall-clock stamps (100 MHz) per workgroup, or null

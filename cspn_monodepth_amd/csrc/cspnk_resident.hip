@@ -826,9 +826,55 @@ int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const
                                    const cspn_resident_plan* plan, cspn_stream_t stream) {
     if (!guided || !x0 || !history || !wk_out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1)
         return fail("cspnk_forward_resident_history: bad arguments");
+    if (K == 5 && g_dtype == CSPN_F16) {
+        // BASELINE config 3's training forward: the dot-product kernel (cspnk_d2.hip) with fp16 planes — x0 / sparse / history are
+        // fp16, every step's state goes to its history plane, wk_out receives the fp16 tap volume (pair-interleaved layout)
+        if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspnk_forward_resident_history: blend %d", blend);
+        if (blend && !sparse) return fail("cspnk_forward_resident_history: blend needs sparse");
+        if (W & 7) return fail("cspnk_forward_resident_history: W must be a multiple of 8");
+        if ((long)24 * H * W >= (1L << 30)) return fail("cspnk_forward_resident_history: guidance images of >= 2^30 elements are not supported");
+        if (!aligned16(guided) || !aligned16(x0) || !aligned16(history) || !aligned16(wk_out) || !aligned16(work) || (sparse && !aligned16(sparse)))
+            return fail("cspnk_forward_resident_history: tensors must be 16-byte aligned");
+        if (seq == 0 || seq > 0x7fffff00u) return fail("cspnk_forward_resident_history: seq must be in [1, 2^31 - 256]");
+        const int ncu = kcu_count();
+        if (ncu <= 0) return fail("cspnk_forward_resident_history: no device");
+        cspn_resident_plan rp{};
+        if (plan) rp = *plan;
+        KGeom g;
+        if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
+            const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
+            if (!kgeom_fill(K, g_dtype, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
+                (long)rp.images_per_launch * g.tiles_x * g.tiles_y > ncu)
+                return fail("cspnk_forward_resident_history: the plan does not fit this problem / device (use cspnk_resident_plan)");
+            g.imgs_per_launch = rp.images_per_launch;
+        } else if (!kres_geometry(K, g_dtype, B, H, W, T, blend, ncu, rp.steps_per_phase, rp.threads, &g)) {
+            return fail("cspnk_forward_resident_history: no resident tiling for K=%d B=%d %dx%d T=%d", K, B, H, W, T);
+        }
+        if (g.no != 1) return fail("cspnk_forward_resident_history: the K = 5 training form needs a one-oct-per-thread tiling");
+        KResArgs a{};
+        a.g = guided; a.x0 = x0; a.sparse = sparse; a.out = nullptr; a.hist = history; a.wk_out = wk_out;
+        const size_t planes = (((size_t)2 * B * H * W * esize(CSPN_F16)) + 15) & ~(size_t)15;
+        a.xbuf = work;
+        a.status = reinterpret_cast<unsigned*>(static_cast<char*>(work) + planes);
+        a.flags = a.status + 4;
+        a.host_err = host_err; a.seq = seq;
+        a.B = B; a.H = H; a.W = W; a.T = T; a.S = g.S;
+        a.tw = g.tw; a.th = g.th; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+        a.wo = g.wo; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr;
+        a.ls = cspn_detail::kres_d2_row_stride(g.wo);
+        a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);
+        a.dbg = rp.debug_stamps;
+        const size_t ldsb = cspn_detail::kres_d2_lds_bytes(g.dr, a.ls, g.threads);
+        if (ldsb > 160 * 1024) return fail("cspnk_forward_resident_history: %zu bytes of LDS", ldsb);
+        a.b0 = 0;
+        a.nb = g.imgs_per_launch < B ? g.imgs_per_launch : B;
+        a.rounds = ceil_div(B, a.nb);
+        a.last_chunk = 1;
+        return cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, 2, kregions_inside_image(g, H, W, T) ? 1 : 0, stream);
+    }
     if (K != 3 || g_dtype != CSPN_F32)
-        return fail("cspnk_forward_resident_history: the training form exists for K = 3 with fp32 guidance (K=%d, dtype %d: use "
-                    "cspn_pac_prepare + cspn_propagate with history)", K, g_dtype);
+        return fail("cspnk_forward_resident_history: the training form exists for K = 3 with fp32 guidance and for K = 5 with fp16 guidance "
+                    "and planes (K=%d, dtype %d: use cspn_pac_prepare + cspn_propagate with history)", K, g_dtype);
     cspn_resident_plan qp{};
     if (plan) qp = *plan;
     qp.threads = 0;

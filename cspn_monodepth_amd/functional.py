@@ -1083,22 +1083,27 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
 
 
 def pac_forward_resident_history(guided, x0, sparse, T):
-    """Training forward of CSPN_ours (K = 3, fp32) as one weight-resident launch per chunk: returns (x_T [view of
-    history[T-1]], history [T,B,H,W], wk [B,8,H,W]) — what pac_prepare + propagate(keep_history=True) return, bit for bit."""
+    """Training forward of CSPN_ours as one weight-resident launch: returns (x_T [view of history[T-1]], history [T,B,H,W],
+    wk tap volume).  K = 3, fp32: what pac_prepare + propagate(keep_history=True) return, bit for bit.  K = 5, fp16 guidance and
+    fp16 planes (BASELINE config 3's shape): the dot-product kernel — the state is rounded to half after every step — with the
+    taps published in the fp16 tap-volume layout; within fp16 rounding of the multi-launch forward."""
     dev = _require_device(guided, x0, sparse)
     B, C, H, W = guided.shape
+    K = int(math.sqrt(C + 1))
     L = _lib.lib()
-    hist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
-    wk = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+    hist = torch.empty((int(T), B, H, W), dtype=x0.dtype, device=dev)
+    wk = _weight_buffer(B, C, H, W, guided.dtype, dev)
     blend = BLEND_SPARSE if sparse is not None else BLEND_NONE
-    rp = _with_spin_limit(_kres_plan_cached(3, B, H, W, int(T), int(blend), dev, 0, CSPN_F32)[1])
+    gdt = _dt(guided)
+    rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, gdt)[1])
 
     def launch(work, seq, host_err_ptr, stream_ptr):
-        return L.cspnk_forward_resident_history(_p(guided), CSPN_F32, 3, _p(x0), _p(sparse), _p(hist), _p(wk), _p(work), seq, host_err_ptr,
+        return L.cspnk_forward_resident_history(_p(guided), gdt, K, _p(x0), _p(sparse), _p(hist), _p(wk), _p(work), seq, host_err_ptr,
                                                 B, H, W, int(T), int(blend), None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=4,
-                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, CSPN_F32), reports_done=True)
+    sdt = _dt(x0)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), reports_done=True)
     _lib.check(ok, "cspnk_forward_resident_history")
     return hist[int(T) - 1], hist, wk
 
@@ -1294,16 +1299,19 @@ class PACFunction(torch.autograd.Function):
             if pac_resident_supported(g, d0, sp, prop_time, plan) is not None:
                 # inference, weight-resident: the softmax taps never leave the registers, no tap volume
                 return pac_forward_resident(g, d0, sp, prop_time).unsqueeze(1)
-        if (need_grad and CX == 1 and not valid_w and C == 8 and guided.dtype == torch.float32 and sdt == torch.float32 and prop_time > 0
+        k3_f32 = C == 8 and guided.dtype == torch.float32 and sdt == torch.float32
+        k5_f16 = C == 24 and guided.dtype == torch.float16 and sdt == torch.float16 and _KRES_STEP_FORM != STEP_FMA
+        if (need_grad and CX == 1 and not valid_w and (k3_f32 or k5_f16) and prop_time > 0
                 and not torch.cuda.is_current_stream_capturing()):
             g = guided if guided.is_contiguous() else guided.contiguous()
             d0 = _plane(x, B, H, W, "x").to(sdt)
-            if pac_resident_supported(g, d0, sp, prop_time, plan) is not None:
+            rpl = pac_resident_supported(g, d0, sp, prop_time, plan)
+            if rpl is not None and (k3_f32 or rpl["quads_per_thread"] == 1):
                 # training, weight-resident (the configuration the reference trains: K = 3, fp32): one launch writes the T depth
                 # planes and publishes the softmax taps for the backward — no prepare pass, no re-streamed tap volume
                 out, hist, wk = pac_forward_resident_history(g, d0, sp, prop_time)
                 ctx.save_for_backward(wk, sp, d0, hist)
-                ctx.K, ctx.prop_time, ctx.plan, ctx.valid_w = 3, int(prop_time), plan, int(valid_w)
+                ctx.K, ctx.prop_time, ctx.plan, ctx.valid_w = (3 if k3_f32 else 5), int(prop_time), plan, int(valid_w)
                 ctx.x_dtype, ctx.g_dtype = x.dtype, guided.dtype
                 return out.unsqueeze(1)
         wk, K = pac_prepare(guided)

@@ -320,10 +320,14 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
                            int state_dtype, void* work, unsigned seq, unsigned* host_err_or_null, int B, int H, int W,
                            int T, int blend, const void* target_or_null, double* acc_or_null, int nslots,
                            const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
-/* Training form of the K x K resident forward (K = 3, fp32 guidance: the configuration the reference trains, unet_ours.py:305,
+/* Training form of the K x K resident forward.  K = 3, fp32 guidance (the configuration the reference trains, unet_ours.py:305,
  * :333): history [T,B,H,W] f32 receives x_1 .. x_T and wk_out [B,8,H,W] f32 the softmax taps once — what cspn_pac_prepare +
  * cspn_propagate(history) hand the backward, bit for bit.  The reverse sweep is cspn3_transposed_resident on wk_out, the
- * tail cspn_pac_backward_tail.  Workspace / seq / host_err (completion word included) / plan as cspn3_forward_resident. */
+ * tail cspn_pac_backward_tail.  K = 5, fp16 guidance (BASELINE config 3's shape): x0 / sparse / history are fp16 planes, the
+ * dot-product kernel (CSPN_STEP_DOT2: state rounded to half after every step) writes every step's state to its plane and
+ * wk_out receives the fp16 tap volume (pair-interleaved layout, as cspn_pac_prepare writes it) — one launch for the whole
+ * batch; the backward is cspn_transpose_weights + cspn_propagate (history) + cspn_pac_backward_tail as for the multi-launch
+ * forward.  Workspace / seq / host_err (completion word included) / plan as cspn3_forward_resident. */
 int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const void* x0, const void* sparse_or_null,
                                    void* history, void* wk_out, void* work, unsigned seq, unsigned* host_err_or_null,
                                    int B, int H, int W, int T, int blend, const cspn_resident_plan* plan_or_null,

@@ -111,3 +111,18 @@ def test_bench_train_whole_step_graph_matches_eager():
     l_on, l_off = res["on"]["loss_first_last"], res["off"]["loss_first_last"]
     assert l_on[0] == l_off[0]
     assert l_off[1] < l_off[0] and abs(l_on[1] - l_off[1]) <= 5e-3 * l_off[1], (l_on, l_off)
+
+
+def test_scale_sweep_script_dry_run_on_one_gpu(tmp_path):
+    """tools/scale_sweep.sh is the one command that produces the north-star table on a multi-GPU node.  It
+    cannot rot: here it runs N = 1, 2 over gloo, oversubscribing the one GPU, for the two inference workloads, and the table
+    tool must print a line per (workload, N) with a whole-job rate and an efficiency."""
+    env = dict(os.environ, PYTHONPATH=ROOT, GPUS="1 2", BACKEND="gloo", STEPS="4", WORKLOADS="nyu kitti", OUT=str(tmp_path), PORT="29720")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert "FAILED" not in out.stdout, out.stdout[-2000:]
+    lines = [l.split() for l in out.stdout.splitlines() if l.split() and l.split()[0] in ("nyu", "kitti")]
+    assert sorted((l[0], int(l[1])) for l in lines) == [("kitti", 1), ("kitti", 2), ("nyu", 1), ("nyu", 2)]
+    assert all(float(l[2]) > 0 for l in lines)
+    d2 = json.load(open(os.path.join(str(tmp_path), "scale_kitti_n2.json")))
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong"

@@ -423,3 +423,47 @@ def test_dot2_form_scores_what_it_stores(c_oracle):
         want = ev.metric_sums(ref.unsqueeze(1), tt)
     assert torch.equal(out, ref)
     assert np.allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 12), (3, 228, 304, 12), (2, 40, 64, 6), (25, 228, 304, 12)], ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_k5_fp16_training_forward_on_the_dot2_kernel(B, H, W, T, sparse, c_oracle):
+    """BASELINE config 3's shape in training: ONE launch of the dot-product kernel writes the T fp16 history planes and publishes
+    the softmax taps in the fp16 tap-volume layout (cspnk_forward_resident_history, K = 5).  The published volume equals
+    cspn_pac_prepare's up to single fp16 ulps on a fraction of a percent of the taps (another, cheaper exponent argument), the
+    history planes stay within fp16 rounding of the multi-launch forward's, and the gradients through the module (this forward,
+    transposed streaming launches, fused tail) agree with the multi-launch path's and the fp64 oracle's within the fp16 tolerances."""
+    from oracle import cspn_oracle as orc
+    K = 5
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=170)
+    xt, gt = dev(x, torch.float16)[:, 0].contiguous(), dev(gd, torch.float16)
+    st = dev(s, torch.float16)[:, 0].contiguous() if sparse else None
+    if F.kres_plan(K, B, H, W, T, int(sparse))["quads_per_thread"] != 1:
+        pytest.skip("no one-oct tiling")
+    with torch.no_grad():
+        wk0, _ = F.pac_prepare(gt)
+        _, hist0 = F.propagate(wk0, xt, st, K, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True,
+                               plan=F.dtype_default_plan(K, wk0.dtype, None))
+        out1, hist1, wk1 = F.pac_forward_resident_history(gt, xt, st, T)
+    F.ensure_resident_ok()
+    assert hist1.dtype == torch.float16 and wk1.shape == wk0.shape and torch.equal(out1, hist1[T - 1])
+    dw = (wk1.float() - wk0.float()).abs()
+    assert float(dw.max()) <= 1.0 / 1024 and float((dw > 0).float().mean()) <= 0.01          # weights are <= 1: an ulp is <= 2^-11
+    scale = float(hist0.float().abs().max())
+    assert float((hist1.float() - hist0.float()).abs().max()) <= 4e-3 * scale
+    if B * H * W > 3 * 228 * 304:
+        return
+    cot = c_oracle.hash_normal(171, 9, (B, 1, H, W))
+    f32 = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)      # noqa: E731
+    wx, wg = orc.pac_backward(f32(x), f32(gd), f32(s), cot, T, np.float64)
+    grads = {}
+    for mode in ("on", "off"):
+        xg, gg = dev(x, torch.float16).requires_grad_(True), dev(gd, torch.float16).requires_grad_(True)
+        with resident(mode):
+            out = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=None)(xg, gg, sparse_depth=dev(s, torch.float16))
+            out.backward(dev(cot, torch.float16))
+        grads[mode] = (xg.grad.float().cpu().numpy(), gg.grad.float().cpu().numpy())
+    F.ensure_resident_ok()
+    for mode in ("on", "off"):
+        assert float(np.abs(grads[mode][0] - wx).max()) <= 1e-2 * float(np.abs(wx).max()), mode
+        assert float(np.abs(grads[mode][1] - wg).max()) <= 3e-2 * float(np.abs(wg).max()), mode

@@ -362,7 +362,13 @@ def test_contended_device_results_equal_uncontended(c_oracle):
     from cspn_monodepth_amd import evaluation as ev
     occ = occupy_lib()
     sink = torch.zeros(4, dtype=torch.int32, device=DEV)
-    side = torch.cuda.Stream()
+    # four side streams, 16 tenant workgroups on each: HIP maps streams onto a handful of hardware queues round robin, and a
+    # tenant that happens to share the launch stream's queue runs before or after the resident launches instead of beside them
+    sides = [torch.cuda.Stream() for _ in range(4)]
+
+    def tenant():
+        for side in sides:
+            assert occ.occupy(16, 120 * 1024, 500000, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
     gt, dt, tg = _config2(c_oracle, seed=313)
     m = pkg.CSPN_new.AffinityPropagate(24, 3)
 
@@ -372,14 +378,14 @@ def test_contended_device_results_equal_uncontended(c_oracle):
         with torch.no_grad():
             for k in range(50):
                 if contended and k % 5 == 0:
-                    assert occ.occupy(64, 120 * 1024, 500000, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+                    tenant()
                 outs.append(m.forward_scored(gt, dt, None, tg, acc))
         total, _ = ev.all_gather_metric_sums(acc)
         for k in range(10):
             g_ = gt[:3].clone().requires_grad_(True)
             d_ = dt[:3].clone().requires_grad_(True)
             if contended:
-                assert occ.occupy(64, 120 * 1024, 500000, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+                tenant()
             for attempt in range(2):
                 try:
                     out = m(g_, d_, None)
