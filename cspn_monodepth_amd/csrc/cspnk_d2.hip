@@ -129,11 +129,24 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
 
     // ---- ownership: thread (sy, sx) owns oct sx of region row sy (tile + halo), one oct per thread ---------------------
     const int wo = a.wo, wr = a.wr;
-    const int sy = tid / wo;
-    const int sx = tid - sy * wo;
+    const int sp = tid / wo;                                // strip row in thread order ...
+    const int sx = tid - sp * wo;
     const bool exch = a.T > a.S;
     const int rx0 = max(exch ? max(0, x0 - a.tw) : 0, min(x0 - a.hxw, W - 8 * wo));
     const int ry0 = max(exch ? max(0, y0 - a.th) : 0, min(y0 - a.hyw, H - wr));
+    // ... and the region row it owns.  -DCSPN_D2_HALO_ROWS_FIRST (an experiment that did not pay): the HALO rows (above
+    // and below the tile) come first in thread order, the tile's own rows after them; the last step of a phase is only needed on
+    // the tile's rows (the halo is re-staged from the neighbours, or the forward is over), so the wavefronts that own nothing but
+    // halo rows sit it out — at config 3 the 12 halo rows are the first four wavefronts, one per SIMD.  The step phases shrink
+    // (4.22 -> 3.74 us) but the neighbour waits grow by as much: 71.3-72.3 vs 72.0-72.5 us per forward, B = 3 29.4 vs 28.5 us.
+    const int i0 = y0 - ry0;                                // first tile row inside the region
+    const int th_in = min(a.th, ry0 + wr - y0);             // tile rows inside the region (the last tile may be cut short)
+#ifdef CSPN_D2_HALO_ROWS_FIRST
+    const int nh = wr - th_in;
+    const int sy = sp >= wr ? sp : (sp < nh ? (sp < i0 ? sp : sp + th_in) : i0 + (sp - nh));
+#else
+    const int sy = sp;
+#endif
     const int xo = rx0 + 8 * sx;
     const int yo = ry0 + sy;
     const bool active = sy < wr;
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
         Oct st0[2];                                           // dr * wo <= 2 * NTH octs (the host checks)
         unsigned st0_in = 0;
         {
-            int row = sy, oc = sx;
+            int row = sp, oc = sx;                            // (the staging enumerates the region linearly by thread id)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int y = yd0 + row, x = rx0 + 8 * oc;
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
         unsigned* const cur = ldsu;
         unsigned* const nxt = ldsu + pp;
         {
-            int tidk = tid, prow = sy, poc = sx;
+            int tidk = tid, prow = sp, poc = sx;
             asm volatile("" : "+v"(tidk), "+v"(prow), "+v"(poc));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -416,9 +429,14 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
                 if (kind != 2 && active) *reinterpret_cast<uint4*>(wrb + (sy + R) * ls + 4 * (sx + 1)) = o;
             };
             const bool any = __ballot(active) != 0ull;       // wavefronts without a single owned row only keep the barriers company
+#ifdef CSPN_D2_HALO_ROWS_FIRST
+            const bool any_tile = __ballot(active && sy >= i0 && sy < i0 + th_in) != 0ull;      // ... without a tile row: the last step
+#else
+            const bool any_tile = any;
+#endif
             for (int s = 0; s < steps; ++s) {
                 const int kind = (s == steps - 1) ? (last_phase ? 2 : 1) : 0;
-                if (any) step(kind, ldsu + (s & 1) * pp, ldsu + ((s + 1) & 1) * pp);
+                if (kind == 0 ? any : any_tile) step(kind, ldsu + (s & 1) * pp, ldsu + ((s + 1) & 1) * pp);
                 if (HIST) hist_step += plane;
                 if (kind == 0) __syncthreads();
             }

@@ -761,6 +761,7 @@ def mark_resident_pending(t=None):
     if st is not None:
         st["dirty"] = True
         st["last_stream"] = torch.cuda.current_stream(dev)
+        st["last_raw"] = st["last_stream"].cuda_stream
         st["lost"] = True                 # a replayed launch cannot be re-run from here: a time-out inside it raises
         st["last_seq"] = None             # (and a pending end-of-backward checkpoint must not poll for a captured seq)
 
@@ -848,10 +849,14 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
                 st["work"].clear()
             work = st["work"][key] = torch.zeros((ws_bytes_fn(),), dtype=torch.uint8, device=dev)
         with _device_guard(dev):
-            cur = torch.cuda.current_stream(dev)
-            last = st["last_stream"]
-            if last is not None and last != cur:
-                cur.wait_stream(last)                   # resident launches never overlap on a device
+            raw = torch._C._cuda_getCurrentRawStream(dev.index)       # (a Stream object per call costs ~1.5 us of the ~20 us call)
+            if raw == st.get("last_raw"):
+                cur = st["last_stream"]
+            else:
+                cur = torch.cuda.current_stream(dev)
+                last = st["last_stream"]
+                if last is not None and last != cur:
+                    cur.wait_stream(last)               # resident launches never overlap on a device
             if st["seq"] > _RES_SEQ_MAX:                # flag values wrap: start over on clean workspaces (zeroed on `cur`,
                 for w_ in st["work"].values():          # behind every earlier resident launch)
                     w_.zero_()
@@ -864,12 +869,13 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
-            ok = launch(work, seq, st["host_err_ptr"], ctypes.c_void_p(cur.cuda_stream))
+            ok = launch(work, seq, st["host_err_ptr"], ctypes.c_void_p(raw))
             if log is not None:
                 ev1.record(cur)
                 log.append((ev0, ev1, 1, T))
             if ok:                                      # (a call that failed at submit has enqueued nothing)
                 st["last_stream"] = cur
+                st["last_raw"] = raw
                 st["dirty"] = True
                 st["last_reports"] = bool(reports_done)
                 if reports_done:                        # training-form launches store `seq` to the completion word
@@ -924,7 +930,9 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
 
     keep_history=True is the training forward: returns (d_T [view of history[T-1]], history [T,B,H,W], w8 [B,8,H,W],
     S [B,H,W]) — the launch writes every step's state to its history plane and publishes the weights and S once."""
-    dev = _require_device(guidance, d0, sparse)
+    dev = guidance.device
+    if not guidance.is_cuda:
+        _require_device(guidance, d0, sparse)          # raises
     B, C, H, W = guidance.shape
     L = _lib.lib()
     hist = w8 = S_out = out = None
@@ -954,12 +962,14 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
     if not keep_history:
         def redo():            # the same call on the multi-launch schedule, into the same tensors (bit-identical: §4.1b)
             from . import evaluation
+            tgp = None if tg is None else tg.reshape(B, H, W)
             if score is not None:
-                _unscore_failed_launch(out, tg, acc)
-            res, _ = propagate_from_guidance(guidance, d0, sparse, T, blend, valid_w=valid_w)
+                _unscore_failed_launch(out, tgp, acc)
+            res, _ = propagate_from_guidance(guidance, d0.reshape(B, H, W), None if sparse is None else sparse.reshape(B, H, W), T, blend,
+                                             valid_w=valid_w)
             out.copy_(res)
             if score is not None:
-                evaluation.metric_sums(out, tg, out=acc)
+                evaluation.metric_sums(out, tgp, out=acc)
 
     ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo)
     _lib.check(ok, "cspn3_forward_resident")
@@ -1369,11 +1379,31 @@ class PACFunction(torch.autograd.Function):
         return gx, gg, None, None, None, None, None
 
 
+_SCORED_FAST = {}      # call signature -> True: cspn3_refine_and_score goes straight to the scored resident launch
+
+
 def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop_time=24, plan=None):
     """Inference forward of the 3x3 module + metrics of the result vs `target` accumulated into `acc`
     (evaluation.new_accumulator) — the eval loop's `model(input)` + `Result.evaluate` for the CSPN stage
     (libs/trainers/single_gpu_trainer.py:129-140) with the metrics fused into the last propagation launch."""
     from . import evaluation
+    # Fast path: an eval loop calls this with the same shapes every time, and at per-GPU shard sizes (one KITTI frame, three NYU
+    # frames) the call's HOST time (~25 us of validation, views and plan look-ups) exceeded the kernel's (19-22 us).  A key made of
+    # everything the checks below depend on remembers that the weight-resident scored launch serves this call; what can still
+    # change from call to call (contiguity, alignment, the module-level switches) is re-checked here.
+    key = None
+    if plan is None and not _DEFAULT_PLANS and acc.dtype == torch.float64:
+        key = (guidance.shape, guidance.stride(), guidance.dtype, blur_depth.shape, blur_depth.dtype,
+               None if sparse_depth is None else (sparse_depth.shape, sparse_depth.dtype), target.shape, target.dtype,
+               acc.shape, int(prop_time), _RESIDENT_MODE, guidance.device)
+        if (_SCORED_FAST.get(key) and blur_depth.is_contiguous() and target.is_contiguous() and acc.is_contiguous()
+                and (sparse_depth is None or sparse_depth.is_contiguous())
+                and not ((guidance.data_ptr() | blur_depth.data_ptr() | target.data_ptr() |
+                          (0 if sparse_depth is None else sparse_depth.data_ptr())) & 15)
+                and blur_depth.device == target.device == guidance.device and (sparse_depth is None or sparse_depth.device == guidance.device)):
+            with torch.no_grad():
+                return forward_resident(guidance, blur_depth, sparse_depth, prop_time, BLEND_NONE if sparse_depth is None else BLEND_SPARSE,
+                                        score=(target, acc)).unsqueeze(1)
     dev = _require_device(guidance, blur_depth, sparse_depth, target)
     W0 = guidance.shape[-1]
     pad = _row_padding(W0, plan)
@@ -1389,6 +1419,10 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
     with torch.no_grad():
         if guidance.dtype == d0.dtype == tg.dtype and resident_supported(guidance, d0, sp, prop_time, plan, tg) is not None:
             out = forward_resident(guidance, d0, sp, prop_time, blend, score=(tg, acc), valid_w=vw)
+            if key is not None and not pad and blur_depth.dim() == 4 and target.dim() == 4 and (sparse_depth is None or sparse_depth.dim() == 4):
+                if len(_SCORED_FAST) > 256:
+                    _SCORED_FAST.clear()
+                _SCORED_FAST[key] = True
             return out.unsqueeze(1)[..., :W0]
         if (_FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan) and guidance.dtype == d0.dtype
                 and tg.dtype == d0.dtype and tg.data_ptr() % 16 == 0):

@@ -44,7 +44,7 @@ for sched in res:
         if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v:
             v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
 dom = [(k, v) for k, v in res.get("fused", {}).items()
-       if k.startswith(("cspn_prop_fused", "cspn3_resident", "cspnk_resident")) and "hbm_bytes_corrected" in v]
+       if k.startswith(("cspn_prop_fused", "cspn3_resident", "cspnk_resident", "cspnk_d2")) and "hbm_bytes_corrected" in v]
 if dom:
     # the default schedule launches two instances of the propagation kernel per forward (the first derives and
     # publishes the weights, the others stream them): bench.py averages over all launches, so does this figure
