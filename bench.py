@@ -601,9 +601,10 @@ def main():
         gather(sums)
         fence()
         sums.zero_()
-        # HIP events around every 4th step only (two records cost ~3 us of stream time each step): still measured live
-        # inside the timed region, `launches_timed` says how many launches the average is over
-        events = F.EventLog(args.steps, every=4 if args.steps >= 20 else 1)
+        # HIP events around every 10th step only (two records cost ~3 us of stream time each step: at every 4th they were 3 % of the
+        # driver's 20-step region): still measured live inside the timed region, `launches_timed` says how many launches the
+        # average is over
+        events = F.EventLog(args.steps, every=10 if args.steps >= 20 else 1)
         F.set_event_log(events)
         fence()
         dbg_host = [] if os.environ.get("BENCH_DEBUG") else None

@@ -20,7 +20,7 @@ HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(CSRC, "cspnk_help
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 7          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 8          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -28,7 +28,7 @@ EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
     "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn_propagate_transposed", "cspn3_propagate_from_guidance",
     "cspn_transpose_weights", "cspn3_resident_plan", "cspn3_resident_workspace_bytes", "cspn3_forward_resident", "cspn3_transposed_resident",
-    "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident", "cspnk_forward_resident_history",
+    "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident", "cspnk_forward_resident_history", "cspnk_transposed_resident",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
     "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
@@ -167,12 +167,14 @@ def _declare(lib):
                                            ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspnk_forward_resident_history.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci,
                                                    ctypes.POINTER(cspn_resident_plan), vp]
+    lib.cspnk_transposed_resident.argtypes = [vp, ci, ci, vp, vp, ci, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci,
+                                              ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn_transpose_weights.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn_grad_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn3_grad_guidance.argtypes = [vp, ci, cl, cl, ci, vp, ci, vp, vp, vp, ci, ci, ci, vp]
     lib.cspn_pac_grad_guided.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.cspn3_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, cl, cl, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
-    lib.cspn_pac_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.cspn_pac_backward_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.cspn_metrics_accumulate.argtypes = [vp, vp, ci, cs, vp, ci, vp]
     geom = ctypes.POINTER(cspn_conv_geometry)
     lib.cspn_pac_out_size.argtypes = [ci, ci, geom, ctypes.POINTER(ci), ctypes.POINTER(ci)]

@@ -127,9 +127,10 @@ struct TailArgs {
     const float* S;       // [B,H,W] (variant 1)
     const void* guidance; // variant 1: [B,C,H,W] WT through strides
     void* gout;           // variant 0: gw f32 [B,NT,H,W]; 1: grad_guidance WT (guidance strides); 2: grad_guided WT
-    float* gd0;           // [B,H,W]
+    void* gd0;            // [B,H,W] f32, or fp16 when gd0_half (the training step on half planes: no cast launch behind the tail)
     long g_bs, g_cs;
     int B, H, W, T, C;
+    int gd0_half;
 };
 
 // History loads of the tail as RAW bits, converted where they are consumed.  For fp32 planes this is the plain load.  For fp16
@@ -295,8 +296,9 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
     }
     {
         const float4 G0 = ld4((T > 0 ? a.ghist + (size_t)(T - 1) * plane : a.g_T) + off);
-        st4(a.gd0 + off, make_float4(G0.x + mm[0] * gsum[0], G0.y + mm[1] * gsum[1], G0.z + mm[2] * gsum[2],
-                                     G0.w + mm[3] * gsum[3]));
+        const float4 gd = make_float4(G0.x + mm[0] * gsum[0], G0.y + mm[1] * gsum[1], G0.z + mm[2] * gsum[2], G0.w + mm[3] * gsum[3]);
+        if (a.gd0_half) st4(static_cast<__half*>(a.gd0) + off, gd);
+        else st4(static_cast<float*>(a.gd0) + off, gd);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -512,12 +514,14 @@ int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, con
 }
 
 int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse, const void* wk,
-                           void* grad_guided, float* gd0, int d_dtype, int w_dtype, int B, int H, int W, int K, int T,
+                           void* grad_guided, void* gd0, int gd0_dtype, int d_dtype, int w_dtype, int B, int H, int W, int K, int T,
                            cspn_stream_t stream) {
     if (!d0 || !g_T || !wk || !grad_guided || !gd0 || (T > 1 && !dhist) || (T > 0 && !ghist)) return fail("cspn_pac_backward_tail: NULL pointer");
     TailArgs a{};
     a.d0 = d0; a.dhist = dhist; a.g_T = g_T; a.ghist = ghist; a.sparse = sparse; a.w = wk; a.gout = grad_guided; a.gd0 = gd0;
     a.B = B; a.H = H; a.W = W; a.T = T;
+    if (gd0_dtype != CSPN_F32 && gd0_dtype != CSPN_F16) return fail("cspn_pac_backward_tail: bad gd0_dtype %d", gd0_dtype);
+    a.gd0_half = gd0_dtype == CSPN_F16;
     if (!tail_vector_ok(a)) return fail("cspn_pac_backward_tail needs W %% 4 == 0 and 16-byte aligned tensors; use "
                                         "cspn_grad_weights + cspn_pac_grad_guided");
     hipStream_t st = static_cast<hipStream_t>(stream);

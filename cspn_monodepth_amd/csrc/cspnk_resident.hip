@@ -38,10 +38,16 @@ constexpr int KRES_THREADS = 512;        // default workgroup; 768 threads (3 wa
 // GT = the guidance dtype: __half -> taps packed two pixels per register (v_fma_mix_f32); float -> fp32 taps, 8 (K*K-1) registers
 // per oct, plain v_fma_f32 (launched for K = 5 only: K = 3 in fp32 — the reference model's own configuration — runs on the quad
 // kernel of cspn_resident.hip in its softmax-weight form, see cspnk_resident_plan).
-template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH = KRES_THREADS, typename GT = __half>
+// TRANS = 1: the backward's reverse sweep  G_t = stencil^T((1-m) G_{t+1})  (pac.py:96-121 run T times) as the same recurrence on
+// the TRANSPOSED taps: tap j = w_{NT-1-j}[p + off_j], gathered ONCE from the forward's fp16 tap volume (pair-interleaved layout,
+// cspn_common.hpp Taps<__half>) instead of being derived by a softmax — what cspn_transpose_kernel + three streaming launches
+// did with a second 80 MB volume.  x0 is G_T = dL/dout (fp32), BLEND means PREMASK (the state that travels — LDS, exchange
+// planes — is (1-m) G, the history planes receive G itself: history[s] = G_{T-1-s}), fp32 planes, no scoring.
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH = KRES_THREADS, typename GT = __half, int TRANS = 0>
 __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs a) {
     constexpr int R = K / 2, NT = K * K - 1;
     constexpr bool PK = std::is_same<GT, __half>::value;
+    static_assert(!TRANS || (PK && std::is_same<ST, float>::value && !SCORE && NO == 1), "the reverse sweep: packed taps, fp32 planes, one oct per thread");
     static_assert(PK || std::is_same<ST, float>::value, "fp32 guidance runs with fp32 depth planes");
     static_assert(R == 1 || R == 2, "K = 3 or 5");
     using IO = StateIO<ST>;
@@ -66,11 +72,27 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     int n_stamp = 0;
     auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
     stamp();
-    // (no completion word: these launches are inference-only; their results are checked where the host synchronises —
-    // functional.ensure_resident_ok — and only the training-form launches of cspn3_resident report to the end-of-backward check)
+    // (no completion word for the inference launches: their results are checked where the host synchronises — functional.
+    // ensure_resident_ok; the reverse sweep reports like cspn3_resident's training forms do: the last workgroup to count itself
+    // out stores `seq` to the second host word)
+    auto count_out = [&]() {
+        if (TRANS && tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == gridDim.x) {
+                __hip_atomic_store(a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.host_err && a.last_chunk) __hip_atomic_store(a.host_err + 1, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
 
-    const ST* __restrict__ x0b = kuniform_ptr(static_cast<const ST*>(a.x0) + (size_t)b * HW);
-    const ST* __restrict__ spb = BLEND ? kuniform_ptr(static_cast<const ST*>(a.sparse) + (size_t)b * HW) : nullptr;
+    // TRANS = 2: the cotangent and the sparse plane arrive as fp16 (the training step on half planes hands them over as they
+    // are: no cast kernels); the state is fp32 all the same, and a.out, when set, receives G_T as fp32 for the backward tail
+    typedef typename std::conditional<TRANS == 2, __half, ST>::type INT;
+    typedef StateIO<INT> IN;
+    typedef typename IN::Oct InOct;
+    typedef typename IN::Pair InPair;
+    const INT* __restrict__ x0b = kuniform_ptr(static_cast<const INT*>(a.x0) + (size_t)b * HW);
+    const INT* __restrict__ spb = BLEND ? kuniform_ptr(static_cast<const INT*>(a.sparse) + (size_t)b * HW) : nullptr;
 
     // ---- ownership: strip (sx, sy) = NO vertically consecutive octs of the weight region (tile + halo) ----------------
     const int wo = a.wo, wr = a.wr;
@@ -96,7 +118,9 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     float* const nxt = lds + pp;
     const int yd0 = ry0 - R;
     const int eo = 4 * (wo + 2);               // offset of the odd-quad array inside a row
-    Oct st0[NO + 1];                           // dr * wo <= (NO + 1) * NTH octs (the host checks)
+    InOct st0[NO + 1];                         // dr * wo <= (NO + 1) * NTH octs (the host checks)
+    InOct sp0[(TRANS && BLEND) ? NO + 1 : 1];
+    InPair spr[2];
     unsigned st0_in = 0;
     const int step_r = NTH / wo, step_q = NTH - step_r * wo;
     {
@@ -106,14 +130,15 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
             const int y = yd0 + row, x = rx0 + 8 * oc;
             const bool in = (row < dr) && y >= 0 && y < H && x < W;
             if (in) st0_in |= 1u << u;
-            st0[u] = IO::ld_oct(x0b, in ? (unsigned)(y * W + x) : 0u);
+            st0[u] = IN::ld_oct(x0b, in ? (unsigned)(y * W + x) : 0u);
+            if (TRANS && BLEND) sp0[u] = IN::ld_oct(spb, in ? (unsigned)(y * W + x) : 0u);      // PREMASK: the sweep starts from (1-m) G_T
             row += step_r; oc += step_q;
             if (oc >= wo) { oc -= wo; ++row; }
         }
     }
     // the R-pixel ring left / right of the region rows: one pair (R = 2) or one pixel (R = 1, read as the pair it sits in)
     // per row and side; 2 * dr <= 2 * NTH items
-    Pair rg[2];
+    InPair rg[2];
     unsigned rg_in = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -122,7 +147,8 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         const int y = yd0 + row, x = side ? rx0 + 8 * wo : rx0 - 2;
         const bool in = (t < 2 * dr) && y >= 0 && y < H && x >= 0 && x < W;
         if (in) rg_in |= 1u << k;
-        rg[k] = IO::ld_pair(x0b, in ? (unsigned)(y * W + x) : 0u);
+        rg[k] = IN::ld_pair(x0b, in ? (unsigned)(y * W + x) : 0u);
+        if (TRANS && BLEND) spr[k] = IN::ld_pair(spb, in ? (unsigned)(y * W + x) : 0u);
     }
 
     // ---- 1. guidance of the owned octs: NT 16-byte loads per oct, all requested before the arithmetic ------------------
@@ -139,7 +165,36 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         const unsigned off = ok ? (unsigned)(y * W + xo) : 0u;
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
-            if constexpr (PK) {
+            if constexpr (TRANS) {
+                // transposed tap j = c: channel NT-1-j of the forward volume at p + off_j.  The volume keeps tap pairs per quad
+                // ([NT/2][HW/4][2][4] halfs): the 8 pixels x+dx .. x+dx+7 of a tap are pieces of two or three quads (8 bytes
+                // each), put together by dword selects (dx even) or 16-bit funnel shifts (dx odd).  Branch-free: safe addresses
+                // + selects, all requested before they are used.
+                const int lin = c < NT / 2 ? c : c + 1;
+                const int dy = lin / K - R, dx = lin % K - R;
+                const int cs = NT - 1 - c;
+                const int ys = y + dy;
+                const bool rok = ok && ys >= 0 && ys < H;
+                const unsigned pq = rok ? ((unsigned)(ys * W + xo) >> 2) : 0u;
+                const unsigned cbase = (unsigned)(cs >> 1) * 2u * HW + ((unsigned)(cs & 1) << 2);      // halfs (HW % 8 == 0: hw4 = HW)
+                const bool lok = rok && xo > 0, r2ok = rok && xo + 8 < W;
+                uint2 q0 = ld8u(atb(gb, (cbase + (pq << 3)) * 2u));
+                uint2 q1 = ld8u(atb(gb, (cbase + ((pq + 1u) << 3)) * 2u));
+                uint2 qm = make_uint2(0u, 0u), q2 = make_uint2(0u, 0u);
+                if (dx < 0) qm = ld8u(atb(gb, (cbase + ((lok ? pq - 1u : pq) << 3)) * 2u));
+                if (dx > 0) q2 = ld8u(atb(gb, (cbase + ((r2ok ? pq + 2u : pq) << 3)) * 2u));
+                if (!rok) { q0 = make_uint2(0u, 0u); q1 = make_uint2(0u, 0u); }
+                if (!lok) qm = make_uint2(0u, 0u);
+                if (!r2ok) q2 = make_uint2(0u, 0u);
+                auto fs = [](unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); };      // (lo.hi, hi.lo)
+                uint4 t;
+                if (dx == -2) t = make_uint4(qm.y, q0.x, q0.y, q1.x);
+                else if (dx == -1) t = make_uint4(fs(q0.x, qm.y), fs(q0.y, q0.x), fs(q1.x, q0.y), fs(q1.y, q1.x));
+                else if (dx == 0) t = make_uint4(q0.x, q0.y, q1.x, q1.y);
+                else if (dx == 1) t = make_uint4(fs(q0.y, q0.x), fs(q1.x, q0.y), fs(q1.y, q1.x), fs(q2.x, q1.y));
+                else t = make_uint4(q0.y, q1.x, q1.y, q2.x);
+                wpk[PK ? i : 0][PK ? c : 0] = t;
+            } else if constexpr (PK) {
                 wpk[i][c] = ld16(atb(gb, ((unsigned)c * HW + off) * 2u));
             } else {
                 const uint4 lo = ld16(atb(gb, ((unsigned)c * HW + off) * 4u)), hi = ld16(atb(gb, ((unsigned)c * HW + off) * 4u + 16u));
@@ -156,8 +211,20 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
 #pragma unroll
         for (int u = 0; u <= NO; ++u) {
             float v[8];
-            IO::to_f8(st0[u], v);
+            IN::to_f8(st0[u], v);
             const bool in = (st0_in >> u) & 1u;
+            if constexpr (TRANS == 2) {
+                // the tile's own octs of G_T, as fp32, for the tail (before the mask)
+                const int y = yd0 + prow, x = rx0 + 8 * poc;
+                if (a.out && in && prow < dr && y >= y0 && y < y0 + a.th && x >= x0 && x < x0 + a.tw)
+                    IO::st_oct(kuniform_ptr(static_cast<ST*>(a.out) + (size_t)b * HW), (unsigned)(y * W + x), IO::from_f8(v));
+            }
+            if (TRANS && BLEND) {
+                float m8[8];
+                IN::to_f8(sp0[(TRANS && BLEND) ? u : 0], m8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= 1.f - sgnf(m8[e]);
+            }
             if (prow < dr) {
                 float* p = cur + prow * ls + 4 * (poc + 1);
                 *reinterpret_cast<float4*>(p) = make_float4(in ? v[0] : 0.f, in ? v[1] : 0.f, in ? v[2] : 0.f, in ? v[3] : 0.f);
@@ -172,7 +239,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
             if (t < 2 * dr) {
                 const int row = t >> 1, side = t & 1;
                 float p0, p1;
-                IO::to_f2(rg[k], p0, p1);
+                IN::to_f2(rg[k], p0, p1);
+                if (TRANS && BLEND) {
+                    float m0, m1;
+                    IN::to_f2(spr[k], m0, m1);
+                    p0 *= 1.f - sgnf(m0); p1 *= 1.f - sgnf(m1);
+                }
                 const bool in = (rg_in >> k) & 1u;
                 const int at = row * ls + (side ? 4 * (wo + 1) : eo + 2);     // E[wo].xy  /  O[-1].zw
                 cur[at] = in ? p0 : 0.f; cur[at + 1] = in ? p1 : 0.f;
@@ -192,7 +264,9 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     // one refined reciprocal, round to nearest even.)  One pixel at a time: 24 temporaries next to the 96 * NO tap registers.
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
-        if constexpr (PK) {
+        if constexpr (TRANS) {
+            // (the gathered taps are final)
+        } else if constexpr (PK) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 unsigned w[NT];                               // the pixel pair q of every channel
@@ -230,16 +304,18 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
             const bool ok = (in_img >> i) & 1u;
             const unsigned off = ok ? (unsigned)((yo0 + i) * W + xo) : 0u;
             float sp[8], dv[8];
-            IO::to_f8(IO::ld_oct(spb, off), sp);
-            IO::to_f8(IO::ld_oct(x0b, off), dv);
+            IN::to_f8(IN::ld_oct(spb, off), sp);
+            IN::to_f8(IN::ld_oct(x0b, off), dv);
             float om[8], md[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float m = ok ? sgnf(sp[e]) : 0.f;
                 om[e] = 1.f - m;
-                md[e] = m * (ok ? dv[e] : 0.f);
+                md[e] = TRANS ? om[e] : m * (ok ? dv[e] : 0.f);      // PREMASK: the private slots hold 1-m, applied to every step's result
             }
-            if constexpr (PK) {
+            if constexpr (TRANS) {
+                // (nothing is folded into the taps: the history receives the unmasked G)
+            } else if constexpr (PK) {
                 unsigned omp[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) omp[q] = pack_h2(om[2 * q], om[2 * q + 1]);
@@ -264,7 +340,8 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     stamp();                                   // weights derived
     // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes ----------------------
     const bool active = r0 < wr;
-    ST* __restrict__ outb = kuniform_ptr(static_cast<ST*>(a.out) + (size_t)b * HW);
+    ST* __restrict__ outb = TRANS ? nullptr : kuniform_ptr(static_cast<ST*>(a.out) + (size_t)b * HW);      // (TRANS: a.out is the G_T copy)
+    ST* hist_step = TRANS ? kuniform_ptr(static_cast<ST*>(a.hist) + (size_t)b * HW) : nullptr;      // plane of the step being computed
     const int n_phase = (a.T + a.S - 1) / a.S;
     const int tile_global = b * tiles_per_img + trem;
     int fin_buf = 0;                           // LDS buffer that receives the final step's (stored) values: the fused metrics read them back
@@ -394,24 +471,25 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                 float u[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) u[e] = acc[i][e];
-                if (BLEND) {
-                    const int q = (min(r0 + i, wr - 1) * wo + sx) * 8;
-                    const float4 ma = *reinterpret_cast<const float4*>(md_lds + q), mb = *reinterpret_cast<const float4*>(md_lds + q + 4);
-                    const float md[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) u[e] += md[e];                     // (1-m) lives in the taps: + m x0
-                }
                 if (!CLEAN) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) u[e] = ((in_img >> i) & 1u) ? u[e] : 0.f;   // zero padding stays exactly zero
                 }
                 const bool inner = (interior >> i) & 1u;
                 const unsigned off = (unsigned)((yo0 + i) * W + xo);
+                if (TRANS && inner) IO::st_oct(hist_step, off, IO::from_f8(u));            // G_t itself goes to its history plane
+                if (BLEND) {
+                    const int q = (min(r0 + i, wr - 1) * wo + sx) * 8;
+                    const float4 ma = *reinterpret_cast<const float4*>(md_lds + q), mb = *reinterpret_cast<const float4*>(md_lds + q + 4);
+                    const float md[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = TRANS ? md[e] * u[e] : u[e] + md[e];      // forward: (1-m) lives in the taps, + m x0; sweep: (1-m) G travels
+                }
                 if (kind != 0) {                         // the state leaves the launch in the plane dtype
                     const Oct o = IO::from_f8(u);
                     if (sizeof(ST) == 2) IO::to_f8(o, u);
                     if (kind == 1) { if (inner) IO::st_oct_dev(xout, off, o); }
-                    else if (inner) IO::st_oct(outb, off, o);
+                    else if (inner && !TRANS) IO::st_oct(outb, off, o);
                 }
                 // (the final step writes LDS too when the metrics are fused: they score the stored values, read back from the
                 // thread's own slots after the loop — sixteen registers carried out of the step cost the hot loop its spill-free form)
@@ -427,6 +505,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         for (int s = 0; s < steps; ++s) {
             const int kind = (s == steps - 1) ? (last_phase ? 2 : 1) : 0;
             if (any) step(kind, lds + (s & 1) * pp, lds + ((s + 1) & 1) * pp);
+            if (TRANS) hist_step += plane;
             if (kind == 2) fin_buf = (s + 1) & 1;
             if (kind == 0) __syncthreads();
         }
@@ -469,9 +548,11 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) qn[e] = __uint_as_float(0x7fc00000u);
                 const Oct o = IO::from_f8(qn);
+                ST* const pz = TRANS ? kuniform_ptr(static_cast<ST*>(a.hist) + (size_t)(a.T - 1) * plane + (size_t)b * HW) : outb;   // G_0 / the refined depth
 #pragma unroll
                 for (int i = 0; i < NO; ++i)
-                    if ((interior >> i) & 1u) IO::st_oct(outb, (unsigned)((yo0 + i) * W + xo), o);
+                    if ((interior >> i) & 1u) IO::st_oct(pz, (unsigned)((yo0 + i) * W + xo), o);
+                count_out();
                 return;
             }
         }
@@ -517,6 +598,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
         }
     }
     stamp();                                   // epilogue done
+    count_out();
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -649,9 +731,9 @@ bool kres_geometry(int K, int gdt, int B, int H, int W, int T, int blend, int nc
     return found;
 }
 
-template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH, typename GT>
+template <int K, int NO, int BLEND, int SCORE, int CLEAN, typename ST, int NTH, typename GT, int TRANS = 0>
 int klaunch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST, NTH, GT>;
+    constexpr auto kern = cspnk_resident<K, NO, BLEND, SCORE, CLEAN, ST, NTH, GT, TRANS>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -817,6 +899,69 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
                                          : klaunch_k<3, float>(a, g.no, g.threads, grid, g.lds_bytes, blend, score, clean, st);
         }
         if (!ok) return 0;
+    }
+    return 1;
+}
+
+int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_T, const void* sparse_f32, int in_dtype, float* g_T_f32_out,
+                              float* history, void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int premask,
+                              const cspn_resident_plan* plan, cspn_stream_t stream) {
+    if (!wk || !g_T || !history || !work || B <= 0 || H <= 0 || W <= 0 || T < 1) return fail("cspnk_transposed_resident: bad arguments");
+    if (K != 5 || w_dtype != CSPN_F16) return fail("cspnk_transposed_resident: K = 5 with an fp16 tap volume (K=%d, dtype %d)", K, w_dtype);
+    if (premask && !sparse_f32) return fail("cspnk_transposed_resident: premask needs sparse");
+    if (in_dtype != CSPN_F32 && in_dtype != CSPN_F16) return fail("cspnk_transposed_resident: bad in_dtype %d", in_dtype);
+    if (g_T_f32_out && (in_dtype != CSPN_F16 || !aligned16(g_T_f32_out)))
+        return fail("cspnk_transposed_resident: g_T_f32_out goes with fp16 inputs (16-byte aligned)");
+    if (W & 7) return fail("cspnk_transposed_resident: W must be a multiple of 8");
+    if ((long)24 * H * W >= (1L << 30)) return fail("cspnk_transposed_resident: tap volumes of >= 2^30 elements per image are not supported");
+    if (!aligned16(wk) || !aligned16(g_T) || !aligned16(history) || !aligned16(work) || (sparse_f32 && !aligned16(sparse_f32)))
+        return fail("cspnk_transposed_resident: tensors must be 16-byte aligned");
+    if (seq == 0 || seq > 0x7fffff00u) return fail("cspnk_transposed_resident: seq must be in [1, 2^31 - 256]");
+    const int ncu = kcu_count();
+    if (ncu <= 0) return fail("cspnk_transposed_resident: no device");
+    const int blend = premask ? 1 : 0;
+    cspn_resident_plan rp{};
+    if (plan) rp = *plan;
+    KGeom g;
+    if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
+        const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
+        if (!kgeom_fill(K, CSPN_F16, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
+            (long)rp.images_per_launch * g.tiles_x * g.tiles_y > ncu)
+            return fail("cspnk_transposed_resident: the plan does not fit this problem / device (use cspnk_resident_plan)");
+        g.imgs_per_launch = rp.images_per_launch;
+    } else if (!kres_geometry(K, CSPN_F16, B, H, W, T, blend, ncu, rp.steps_per_phase, rp.threads, &g)) {
+        return fail("cspnk_transposed_resident: no resident tiling for K=%d B=%d %dx%d T=%d", K, B, H, W, T);
+    }
+    if (g.no != 1) return fail("cspnk_transposed_resident: needs a one-oct-per-thread tiling");
+    KResArgs a{};
+    a.g = wk; a.x0 = g_T; a.sparse = premask ? sparse_f32 : nullptr; a.out = g_T_f32_out; a.hist = history;
+    const int tr = in_dtype == CSPN_F16 ? 2 : 1;
+    const size_t planes = (((size_t)2 * B * H * W * esize(CSPN_F32)) + 15) & ~(size_t)15;
+    a.xbuf = work;
+    a.status = reinterpret_cast<unsigned*>(static_cast<char*>(work) + planes);
+    a.flags = a.status + 4;
+    a.host_err = host_err; a.seq = seq;
+    a.B = B; a.H = H; a.W = W; a.T = T; a.S = g.S;
+    a.tw = g.tw; a.th = g.th; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+    a.wo = g.wo; a.wr = g.wr; a.hxw = g.hxw; a.hyw = g.hyw; a.dr = g.dr; a.ls = g.ls;
+    a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);
+    a.dbg = rp.debug_stamps;
+    const bool clean = kregions_inside_image(g, H, W, T);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
+        a.b0 = b0;
+        a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
+        a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
+        const int grid = a.nb * g.tiles_x * g.tiles_y;
+        int ok = 0;
+#define KT_CASE(BL, CL, NTHR) \
+        if (!ok && blend == BL && (int)clean == CL && g.threads == NTHR) \
+            ok = tr == 2 ? klaunch_inst<5, 1, BL, 0, CL, float, NTHR, __half, 2>(a, grid, g.lds_bytes, st) \
+                         : klaunch_inst<5, 1, BL, 0, CL, float, NTHR, __half, 1>(a, grid, g.lds_bytes, st)
+        KT_CASE(0, 0, 768); KT_CASE(0, 1, 768); KT_CASE(1, 0, 768); KT_CASE(1, 1, 768);
+        KT_CASE(0, 0, 512); KT_CASE(0, 1, 512); KT_CASE(1, 0, 512); KT_CASE(1, 1, 512);
+#undef KT_CASE
+        if (!ok) return cspn_detail::last_error()[0] ? 0 : fail("cspnk_transposed_resident: no instance for %d threads", g.threads);
     }
     return 1;
 }

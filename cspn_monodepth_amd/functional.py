@@ -924,6 +924,33 @@ def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
     return ghist
 
 
+def pac_transposed_resident(wk, g_T, sparse, T):
+    """K = 5 reverse sweep on the forward's fp16 tap volume as weight-resident launches.  Returns (G_T as fp32 [B,H,W], ghist
+    [T,B,H,W] f32 = G_{T-1} .. G_0).  The transposed taps are gathered once per launch and stay packed in registers; no
+    transposed copy of the volume.  g_T / sparse: both fp32, or both fp16 (the kernel converts where it stages them and writes
+    the fp32 G_T the tail reads: planes 0 and 1.. of one allocation)."""
+    dev = _require_device(wk, g_T, sparse)
+    B, H, W = g_T.shape
+    L = _lib.lib()
+    half_in = g_T.dtype == torch.float16
+    if sparse is not None and sparse.dtype != g_T.dtype:
+        raise ValueError("pac_transposed_resident: g_T and sparse must share a dtype")
+    planes = torch.empty((int(T) + int(half_in), B, H, W), dtype=torch.float32, device=dev)
+    g32, ghist = (planes[0], planes[1:]) if half_in else (g_T, planes)
+    premask = int(sparse is not None)
+    rp = _with_spin_limit(_kres_plan_cached(5, B, H, W, int(T), premask, dev, 0, CSPN_F16)[1])
+
+    def launch(work, seq, host_err_ptr, stream_ptr):
+        return L.cspnk_transposed_resident(_p(wk), CSPN_F16, 5, _p(g_T), _p(sparse), _dt(g_T), _p(g32) if half_in else None, _p(ghist),
+                                           _p(work), seq, host_err_ptr, B, H, W, int(T), premask,
+                                           None if rp is None else ctypes.byref(rp), stream_ptr)
+
+    ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=4,
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, CSPN_F32), reports_done=True)
+    _lib.check(ok, "cspnk_transposed_resident")
+    return g32, ghist
+
+
 def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None,
                      keep_history=False):
     """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it.
@@ -1130,7 +1157,7 @@ def transpose_weights(w, K, H, W):
 
 def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
     """G_T = dL/dout, G_t = stencil^T((1-m) G_{t+1}): the forward kernel on the transposed weights.
-    Returns (g_T [B,H,W] f32 — grad_out itself, not a copy —, ghist [T,B,H,W] f32 in backward order:
+    Returns (g_T [B,H,W] f32 — grad_out itself, not a copy, when it is fp32 —, ghist [T,B,H,W] f32 in backward order:
     ghist[s] = G_{T-1-s}; None when T == 0)."""
     dev = w.device
     B, H, W = grad_out.shape[0], grad_out.shape[-2], grad_out.shape[-1]
@@ -1138,6 +1165,16 @@ def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
     if g_T.data_ptr() % 16:
         g_T = g_T.clone()
     ghist = None
+    if (T > 0 and K == 5 and w.dtype == torch.float16 and w.dim() == 3 and W % 8 == 0 and not valid_w
+            and (sparse is None or sparse.data_ptr() % 16 == 0) and _RESIDENT_MODE != "off" and plan is None
+            and _DEFAULT_PLANS.get(5) is None and 24 * H * W < (1 << 30) and not torch.cuda.is_current_stream_capturing()
+            and os.environ.get("CSPN_REVERSE_SWEEP", "auto") == "auto"
+            and (_kres_plan_cached(5, B, H, W, int(T), int(sparse is not None), dev, 0, CSPN_F16)[0] or {}).get("quads_per_thread") == 1):
+        # weight-resident reverse sweep on the forward's fp16 volume; half cotangent / sparse planes go in as they are
+        if g_T.dtype == torch.float16 and (sparse is None or sparse.dtype == torch.float16):
+            return pac_transposed_resident(w, g_T, sparse, T)
+        return pac_transposed_resident(w, g_T.float(), None if sparse is None else sparse.float(), T)
+    g_T = g_T.float()
     if T > 0:
         sp32 = None if sparse is None else sparse.float()
         L = _lib.lib()
@@ -1349,7 +1386,7 @@ class PACFunction(torch.autograd.Function):
         K, T = ctx.K, ctx.prop_time
         NT = K * K - 1
         L = _lib.lib()
-        go = grad_out.contiguous().float()
+        go = grad_out.contiguous()          # _reverse_sweep converts where its launches need fp32 (the K = 5 resident sweep takes half)
         gg_sum, gxs = None, []
         for c in range(CX):
             d0, hist = planes[2 * c], planes[2 * c + 1]
@@ -1357,9 +1394,9 @@ class PACFunction(torch.autograd.Function):
             _check_resident_at_end_of_backward(wk.device)
             gg = torch.empty((B, NT, H, W), dtype=ctx.g_dtype, device=wk.device)
             if _tail_vector_ok(W, wk, d0, sp, hist, gg):
-                gx0 = torch.empty((B, H, W), dtype=torch.float32, device=wk.device)
+                gx0 = torch.empty((B, H, W), dtype=ctx.x_dtype if ctx.x_dtype == torch.float16 else torch.float32, device=wk.device)
                 with _device_guard(wk.device):
-                    ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(d0),
+                    ok = L.cspn_pac_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(wk), _p(gg), _p(gx0), _dt(gx0), _dt(d0),
                                                   _dt(wk), B, H, W, K, T, _stream(wk.device))
                 _lib.check(ok, "cspn_pac_backward_tail")
             else:

@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 7
+#define CSPN_ABI_VERSION 8
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -194,8 +194,9 @@ int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, con
                         const void* guidance, long g_batch_stride, long g_chan_stride, int C, const void* w8,
                         const float* s, void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T,
                         cspn_stream_t stream);
+/* gd0_dtype: CSPN_F32, or CSPN_F16 — dL/dx0 rounded to half where it is produced (what a cast of the fp32 plane gives). */
 int cspn_pac_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
-                           const void* wk, void* grad_guided, float* gd0, int d_dtype, int w_dtype,
+                           const void* wk, void* grad_guided, void* gd0, int gd0_dtype, int d_dtype, int w_dtype,
                            int B, int H, int W, int K, int T, cspn_stream_t stream);
 
 /* ---- evaluation (libs/metrics.py:49-83, base_model.py:28-73) ------------ */
@@ -326,12 +327,25 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
  * tail cspn_pac_backward_tail.  K = 5, fp16 guidance (BASELINE config 3's shape): x0 / sparse / history are fp16 planes, the
  * dot-product kernel (CSPN_STEP_DOT2: state rounded to half after every step) writes every step's state to its plane and
  * wk_out receives the fp16 tap volume (pair-interleaved layout, as cspn_pac_prepare writes it) — one launch for the whole
- * batch; the backward is cspn_transpose_weights + cspn_propagate (history) + cspn_pac_backward_tail as for the multi-launch
- * forward.  Workspace / seq / host_err (completion word included) / plan as cspn3_forward_resident. */
+ * batch; the backward is cspnk_transposed_resident (or cspn_transpose_weights + cspn_propagate (history)) +
+ * cspn_pac_backward_tail.  Workspace / seq / host_err (completion word included) / plan as cspn3_forward_resident. */
 int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const void* x0, const void* sparse_or_null,
                                    void* history, void* wk_out, void* work, unsigned seq, unsigned* host_err_or_null,
                                    int B, int H, int W, int T, int blend, const cspn_resident_plan* plan_or_null,
                                    cspn_stream_t stream);
+
+/* The K = 5 reverse sweep of the backward, G_t = stencil^T((1-m) G_{t+1}), t = T-1..0 (pac.py:96-121 applied T times), as
+ * weight-resident launches: the transposed taps w_{23-j}[p + off_j] are gathered once from the forward's fp16 tap volume `wk`
+ * (the layout cspn_pac_prepare / cspnk_forward_resident_history write) and stay packed in registers; fp32 state.  history
+ * [T,B,H,W] f32 receives G_{T-1} .. G_0 in that order; premask != 0 applies (1-m), m = sign(sparse).  Bit-identical to
+ * cspn_transpose_weights + cspn_propagate (history, CSPN_BLEND_PREMASK) on the same inputs.  in_dtype = dtype of g_T and sparse:
+ * CSPN_F32, or CSPN_F16 — the training step on half planes hands its cotangent and sparse plane over as they are (no cast
+ * launches); the state is fp32 either way, and g_T_f32_out [B,H,W], when given, receives G_T as fp32 for cspn_pac_backward_tail.
+ * Workspace (cspnk_resident_workspace_bytes with CSPN_F32), seq, host_err (completion word included), plan: as
+ * cspn3_transposed_resident. */
+int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_T, const void* sparse_or_null, int in_dtype,
+                              float* g_T_f32_out_or_null, float* history, void* work, unsigned seq, unsigned* host_err_or_null,
+                              int B, int H, int W, int T, int premask, const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
 
 /* A/B + test switch (process-wide): on != 0 makes every cspn_pac_* entry skip its LDS-tiled kernels and run the generic
  * one-quad-per-thread kernels; the previous setting is stored to *previous_or_null.  The initial value is read once from

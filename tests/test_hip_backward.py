@@ -108,7 +108,7 @@ def test_fused_tail_equals_unfused_path(sparse, c_oracle):
         ref, out = torch.empty_like(gd), torch.full_like(gd, float("nan"))
         gx = torch.empty_like(gx_ref)
         assert L.cspn_pac_grad_guided(P(wk), 0, P(gw), P(ref), 0, B, H, W, K, st)
-        assert L.cspn_pac_backward_tail(P(d0), P(hist), P(g_T), P(ghist), P(sp), P(wk), P(out), P(gx), 0, 0, B, H, W, K, T, st)
+        assert L.cspn_pac_backward_tail(P(d0), P(hist), P(g_T), P(ghist), P(sp), P(wk), P(out), P(gx), 0, 0, 0, B, H, W, K, T, st)
         torch.cuda.synchronize()
         assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
         assert torch.allclose(gx, gx_ref, rtol=1e-5, atol=1e-6)

@@ -471,3 +471,36 @@ def test_k5_fp16_training_forward_on_the_dot2_kernel(B, H, W, T, sparse, c_oracl
     for mode in ("on", "off"):
         assert float(np.abs(grads[mode][0] - wx).max()) <= 1e-2 * float(np.abs(wx).max()), mode
         assert float(np.abs(grads[mode][1] - wg).max()) <= 3e-2 * float(np.abs(wg).max()), mode
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 12), (3, 228, 304, 12), (2, 40, 64, 6), (25, 228, 304, 12), (1, 352, 1216, 12), (2, 13, 24, 5),
+                                     (5, 60, 72, 7)], ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_k5_resident_reverse_sweep_equals_the_streaming_one(B, H, W, T, sparse, c_oracle):
+    """cspnk_transposed_resident (K = 5 reverse sweep of pac.py:96-121's backward, transposed taps gathered once from the forward's
+    fp16 tap volume and kept packed in registers) against cspn_transpose_weights + the streaming launches on the same volume and
+    cotangent: every G_t plane, bit for bit (same taps, same summation order, fp32 state)."""
+    K = 5
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=180)
+    gt = dev(gd, torch.float16)
+    sp = dev(s, torch.float16)[:, 0].contiguous() if sparse else None
+    cot = dev(c_oracle.hash_normal(181, 9, (B, H, W)))
+    rp = F.kres_plan(K, B, H, W, T, int(sparse))
+    if rp is None or rp["quads_per_thread"] != 1:
+        pytest.skip("no one-oct tiling")
+    with torch.no_grad():
+        wk, _ = F.pac_prepare(gt)
+        with resident("off"):
+            _, ref = F._reverse_sweep(wk, K, T, sp, cot, None)
+            _, ref16 = F._reverse_sweep(wk, K, T, sp, cot.half().float(), None)
+        with resident("on"):
+            g32, out = F._reverse_sweep(wk, K, T, sp, cot, None)
+            _, direct = F.pac_transposed_resident(wk, cot, None if sp is None else sp.float(), T)
+            # fp16 cotangent and sparse plane as the half training step hands them over: converted where they are staged
+            g16, out16 = F._reverse_sweep(wk, K, T, sp, cot.half(), None)
+    F.ensure_resident_ok()
+    assert g32 is cot or g32.data_ptr() == cot.data_ptr()
+    assert torch.equal(direct, out)
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    assert g16.dtype == torch.float32 and torch.equal(g16, cot.half().float())
+    assert torch.equal(out16, ref16), float((out16 - ref16).abs().max())
