@@ -2,6 +2,8 @@
 // cspn_prop_fused on the transposed weights).  See DESIGN.md §4.2.
 #include "cspn_common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -391,10 +393,259 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
     }
 }
 
+// ---- K = 5: the tail split by TAP ROWS over two half-workgroups -------------------------------------------------------------
+// A quad of the 5 x 5 tail carries 24 x 4 accumulators: with the window and two steps of loads in flight that is the whole
+// 256-register file, ONE wavefront per SIMD, and every load trip of the stream is exposed (cspn_grad_tail<5, half, half, 2>:
+// 142 us for 294 MB = 0.26 of the HBM peak, profiles/r04_kernel_stats_train_leg_pac5.csv).  Here threads 0..127 of a workgroup
+// own the taps above the centre (rows dy = -2, -1 and the left half of row 0: j = 0..11) of 128 quads, threads 128..255 the
+// mirror half (j = 12..23) of the SAME quads: 48 accumulators and 3 window rows per thread.  The softmax backward needs
+// sum_k (1-m) acc_k sm_k over all 24 taps: each half sums its 12 and the two partial sums meet in LDS (one barrier per
+// workgroup, after the stream).  Strip-end patches are ONE aligned pair load per row and side (x - 2 / x + 4) instead of two
+// scalar loads.  Loads are raw bits from always-valid addresses, zeroed where they are consumed (see TailRaw).
+template <typename DT> struct TailPair;
+template <> struct TailPair<float> {
+    typedef float2 P;
+    static __device__ __forceinline__ P ld(const float* p) { return *reinterpret_cast<const float2*>(p); }
+    static __device__ __forceinline__ void f2(P v, float& a, float& b) { a = v.x; b = v.y; }
+    static __device__ __forceinline__ P zero() { return make_float2(0.f, 0.f); }
+};
+template <> struct TailPair<__half> {
+    typedef unsigned P;
+    static __device__ __forceinline__ P ld(const __half* p) { return *reinterpret_cast<const unsigned*>(p); }
+    static __device__ __forceinline__ void f2(P v, float& a, float& b) {
+        asm volatile("" : "+v"(v));
+        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&v));
+        a = f.x; b = f.y;
+    }
+    static __device__ __forceinline__ P zero() { return 0u; }
+};
+template <typename DT> struct TailQuad;
+template <> struct TailQuad<float> {
+    typedef float4 Q;
+    static __device__ __forceinline__ Q ld(const float* p) { return ld4(p); }
+    static __device__ __forceinline__ float4 f4(Q q) { return q; }
+};
+template <> struct TailQuad<__half> {
+    typedef uint2 Q;
+    static __device__ __forceinline__ Q ld(const __half* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ float4 f4(Q q) { return TailRaw<__half>::f4(q); }
+};
+
+#ifndef CSPN_TAIL5_UNR
+#define CSPN_TAIL5_UNR 2
+#endif
+
+template <int NT0, int CNT>
+__device__ __forceinline__ void load_tap_range_quad(const float* img, size_t p, size_t HW, float (&out)[CNT][4]) {
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        const float4 v = ld4(img + (size_t)(NT0 + j) * HW + p);
+        out[j][0] = v.x; out[j][1] = v.y; out[j][2] = v.z; out[j][3] = v.w;
+    }
+}
+template <int NT0, int CNT>
+__device__ __forceinline__ void load_tap_range_quad(const __half* img, size_t p, size_t HW, float (&out)[CNT][4]) {
+    static_assert(NT0 % 2 == 0 && CNT % 2 == 0, "whole tap pairs");
+    const size_t pair_stride = 2 * Taps<__half>::hw4(HW);
+#pragma unroll
+    for (int jp = 0; jp < CNT / 2; ++jp) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(img + (size_t)(NT0 / 2 + jp) * pair_stride + 2 * p);
+        const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+        const float2 c = __half22float2(*reinterpret_cast<const __half2*>(&raw.z));
+        const float2 d = __half22float2(*reinterpret_cast<const __half2*>(&raw.w));
+        out[2 * jp][0] = a.x; out[2 * jp][1] = a.y; out[2 * jp][2] = b.x; out[2 * jp][3] = b.y;
+        out[2 * jp + 1][0] = c.x; out[2 * jp + 1][1] = c.y; out[2 * jp + 1][2] = d.x; out[2 * jp + 1][3] = d.y;
+    }
+}
+
+template <typename DT, typename WT, int VARIANT, int HALF>
+__device__ __forceinline__ void tail5_half(const TailArgs& a, float4 (*xdot)[128]) {
+    constexpr int K = 5, R = 2, NT = 24, NH = 12, RR = R + 1, WIN = 4 + 2 * R;
+    constexpr int DY0 = HALF ? 0 : -R;                  // window row rr holds image row y + DY0 + rr
+    constexpr int UNR = CSPN_TAIL5_UNR;
+    typedef TailQuad<DT> QD;
+    typedef TailPair<DT> PR;
+    const int H = a.H, W = a.W, T = a.T;
+    const int WQ = W >> 2;
+    const size_t HW = (size_t)H * W;
+    const size_t plane = (size_t)a.B * HW;
+    const size_t nquads = (size_t)a.B * H * WQ;
+    const int ql = threadIdx.x & 127;
+    const size_t q = (size_t)xcd_contiguous_id(blockIdx.x, gridDim.x) * 128 + ql;
+    const bool live = q < nquads;
+    const size_t qq = live ? q : 0;
+    const int b = (int)(qq / ((size_t)H * WQ));
+    const int rem = (int)(qq - (size_t)b * H * WQ);
+    const int y = rem / WQ, qx = rem - y * WQ, x = qx * 4;
+    const int lane = threadIdx.x & 63;
+    const bool fix_left = (qx == 0) || (lane == 0);
+    const bool fix_right = (qx == WQ - 1) || (lane == 63);
+    const size_t off = (size_t)b * HW + (size_t)y * W + x;
+    const DT* d0 = static_cast<const DT*>(a.d0);
+    const DT* dh = static_cast<const DT*>(a.dhist);
+
+    float acc[NH][4];
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // row offsets of the window, clamped to valid rows (invalid ones are zeroed at the consumer), and the patch columns
+    unsigned rowoff[RR];
+    bool rowok[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+        const int row = y + DY0 + rr;
+        rowok[rr] = row >= 0 && row < H;
+        rowoff[rr] = (unsigned)((rowok[rr] ? row : y) * W);
+    }
+    const bool has_left = x > 0, has_right = x + 4 < W;
+    const int xl = has_left ? x - 2 : x, xr = has_right ? x + 4 : x;
+
+    for (int t0 = 0; t0 < T; t0 += UNR) {
+        float4 Gq[UNR];
+        typename QD::Q midq[UNR][RR];
+        typename PR::P lf[UNR][RR], rf[UNR][RR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int t = t0 + u;
+            const int tc = t < T ? t : T - 1;           // a step past the end re-reads the last one; its G is zeroed below
+            const DT* d = ((tc == 0) ? d0 : dh + (size_t)(tc - 1) * plane) + (size_t)b * HW;
+            const float* gsrc = (tc == T - 1) ? a.g_T : a.ghist + (size_t)(T - 2 - tc) * plane;      // G_{t+1}
+            Gq[u] = ld4(gsrc + off);
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr) {
+                const DT* rp = d + rowoff[rr];
+                midq[u][rr] = QD::ld(rp + x);
+                lf[u][rr] = PR::zero(); rf[u][rr] = PR::zero();
+                if (HALF == 1 && rr == 0) {
+                    if (fix_right) rf[u][rr] = PR::ld(rp + xr);                     // row 0 of the lower half: taps right of the centre only
+                } else if (HALF == 0 && rr == RR - 1) {
+                    if (fix_left) lf[u][rr] = PR::ld(rp + xl);                      // row 0 of the upper half: taps left of the centre only
+                } else {
+                    if (fix_left) lf[u][rr] = PR::ld(rp + xl);
+                    if (fix_right) rf[u][rr] = PR::ld(rp + xr);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const bool tv = live && (t0 + u) < T;
+            const float g4[4] = {tv ? Gq[u].x : 0.f, tv ? Gq[u].y : 0.f, tv ? Gq[u].z : 0.f, tv ? Gq[u].w : 0.f};
+            float win[RR][WIN];
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr) {
+                const bool rok = rowok[rr];
+                const float4 mq = QD::f4(midq[u][rr]);
+                const float m4[4] = {rok ? mq.x : 0.f, rok ? mq.y : 0.f, rok ? mq.z : 0.f, rok ? mq.w : 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) win[rr][R + c] = m4[c];
+                float l0, l1, r0, r1;
+                PR::f2(lf[u][rr], l0, l1);
+                PR::f2(rf[u][rr], r0, r1);
+                const bool lok = rok && has_left, rgt = rok && has_right;
+                const float lv[2] = {lok ? l0 : 0.f, lok ? l1 : 0.f}, rv[2] = {rgt ? r0 : 0.f, rgt ? r1 : 0.f};
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const float l = dpp_from_prev_lane(m4[4 - R + c]);
+                    const float r = dpp_from_next_lane(m4[c]);
+                    win[rr][c] = fix_left ? lv[c] : l;
+                    win[rr][R + 4 + c] = fix_right ? rv[c] : r;
+                }
+            }
+            if (HALF == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gsum[e] += g4[e];
+            }
+#pragma unroll
+            for (int jl = 0; jl < NH; ++jl) {
+                constexpr int KK2 = (K * K) / 2;
+                const int j = HALF * NH + jl;
+                const int lin = j < KK2 ? j : j + 1;
+                const int dy = lin / K - R, dx = lin % K - R;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[jl][e] = fmaf(g4[e], win[dy - DY0][e + dx + R], acc[jl][e]);
+            }
+        }
+    }
+
+    float om[4] = {1.f, 1.f, 1.f, 1.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.sparse && live) {
+        const float4 sp = sgn4(ld4(static_cast<const DT*>(a.sparse) + off));
+        mm[0] = sp.x; mm[1] = sp.y; mm[2] = sp.z; mm[3] = sp.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) om[e] = 1.f - mm[e];
+    }
+    if (HALF == 0 && live) {
+        const float4 G0 = ld4((T > 0 ? a.ghist + (size_t)(T - 1) * plane : a.g_T) + off);
+        const float4 gd = make_float4(G0.x + mm[0] * gsum[0], G0.y + mm[1] * gsum[1], G0.z + mm[2] * gsum[2], G0.w + mm[3] * gsum[3]);
+        if (a.gd0_half) st4(static_cast<__half*>(a.gd0) + off, gd);
+        else st4(static_cast<float*>(a.gd0) + off, gd);
+    }
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] *= om[e];
+
+    if constexpr (VARIANT == 0) {
+        if (live) {
+            float* gw = static_cast<float*>(a.gout) + (size_t)b * NT * HW + (size_t)y * W + x;
+#pragma unroll
+            for (int j = 0; j < NH; ++j) st4(gw + (size_t)(HALF * NH + j) * HW, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
+        }
+    } else {
+        const WT* wk = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(NT, HW);
+        float sm[NH][4];
+        load_tap_range_quad<HALF * NH, NH>(wk, live ? (size_t)y * W + x : 0, HW, sm);
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NH; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot[e] = fmaf(sm[j][e], acc[j][e], dot[e]);
+        xdot[HALF][ql] = make_float4(dot[0], dot[1], dot[2], dot[3]);
+        __syncthreads();
+        const float4 od = xdot[1 - HALF][ql];
+        // (upper half's sum) + (lower half's sum), in that order in both halves: the two agree bit for bit
+        if (HALF == 0) { dot[0] += od.x; dot[1] += od.y; dot[2] += od.z; dot[3] += od.w; }
+        else { dot[0] = od.x + dot[0]; dot[1] = od.y + dot[1]; dot[2] = od.z + dot[2]; dot[3] = od.w + dot[3]; }
+        if (live) {
+            WT* gg = static_cast<WT*>(a.gout) + (size_t)b * NT * HW + (size_t)y * W + x;   // plain [B,NT,H,W] gradient
+#pragma unroll
+            for (int j = 0; j < NH; ++j)
+                st4(gg + (size_t)(HALF * NH + j) * HW, make_float4(sm[j][0] * (acc[j][0] - dot[0]), sm[j][1] * (acc[j][1] - dot[1]),
+                                                                   sm[j][2] * (acc[j][2] - dot[2]), sm[j][3] * (acc[j][3] - dot[3])));
+        }
+    }
+}
+
+template <typename DT, typename WT, int VARIANT>
+__global__ __launch_bounds__(256) void cspn_grad_tail5(const TailArgs a) {
+    static_assert(VARIANT == 0 || VARIANT == 2, "raw dL/dw or the softmax epilogue");
+    __shared__ float4 xdot[2][128];
+    if (threadIdx.x < 128) tail5_half<DT, WT, VARIANT, 0>(a, xdot);          // wave-uniform: waves 0, 1 / 2, 3
+    else tail5_half<DT, WT, VARIANT, 1>(a, xdot);
+}
+
+bool tail5_split_enabled() {
+    static const int on = [] { const char* e = getenv("CSPN_TAIL5_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
 template <int K, typename DT, typename WT>
 int launch_tail(const TailArgs& a, int variant, hipStream_t st) {
     const size_t nquads = (size_t)a.B * a.H * (a.W / 4);
     const int grid = (int)((nquads + 255) / 256);
+    if constexpr (K == 5) {
+        if ((variant == 0 || variant == 2) && tail5_split_enabled()) {
+            const int grid5 = (int)((nquads + 127) / 128);
+            if (variant == 0) hipLaunchKernelGGL((cspn_grad_tail5<DT, WT, 0>), dim3(grid5), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((cspn_grad_tail5<DT, WT, 2>), dim3(grid5), dim3(256), 0, st, a);
+            HIP_OK(hipGetLastError());
+            return 1;
+        }
+    }
     if (variant == 0) hipLaunchKernelGGL((cspn_grad_tail<K, DT, WT, 0>), dim3(grid), dim3(256), 0, st, a);
     else if (variant == 2) hipLaunchKernelGGL((cspn_grad_tail<K, DT, WT, 2>), dim3(grid), dim3(256), 0, st, a);
     else if constexpr (K == 3) hipLaunchKernelGGL((cspn_grad_tail<3, DT, WT, 1>), dim3(grid), dim3(256), 0, st, a);
