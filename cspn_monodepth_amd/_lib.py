@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "cspn_unpool.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "pac_conv2d_s2.hip", "cspn_unpool.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(CSRC, "cspnk_helpers.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
@@ -54,7 +54,7 @@ class cspn_conv_geometry(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "oph", "opw", "transposed")]
 
 
-BENCH_UNRELATED = ("pac_conv2d.hip", "cspn_unpool.hip")       # kernels no bench.py workload launches
+BENCH_UNRELATED = ("pac_conv2d.hip", "pac_conv2d_s2.hip", "cspn_unpool.hip")       # kernels no bench.py workload launches
 
 
 def _source_digest(flags, code_only=False):

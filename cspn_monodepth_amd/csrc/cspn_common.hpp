@@ -24,6 +24,16 @@ int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, vo
 int kres_d2_row_stride(int wo);
 size_t kres_d2_lds_bytes(int dr, int ls, int threads);
 int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, void* stream);   // mode 0 plain, 1 scored, 2 history
+// pac_conv2d_s2.hip: the pixel-adaptive convolution and its gradients for stride 2 x 2, dilation 1, K in {3, 5}, padding K / 2,
+// W % 8 == 0 (launched by the cspn_pac_conv2d* entry points of pac_conv2d.hip when every base pointer is 16-byte aligned)
+struct PacS2Args {
+    int B, C, CK, H, W, Ho, Wo, WQ;      // WQ = Wo / 4 = W / 8 quads per output row
+    int cchunk;                          // channels per blockIdx.y (set by the launcher)
+};
+bool pac_s2_geometry(int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int W);
+int pac_s2_forward(const void* in, const void* kern, void* out, int dtype, int K, const PacS2Args& a, void* stream);
+int pac_s2_grad_input(const void* gout, const void* kern, void* gin, int dtype, int K, const PacS2Args& a, void* stream);
+int pac_s2_grad_kernel(const void* gout, const void* in, void* gk, int dtype, int K, const PacS2Args& a, void* stream);
 }  // namespace cspn_detail
 
 namespace {

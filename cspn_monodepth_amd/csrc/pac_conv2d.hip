@@ -1223,6 +1223,21 @@ bool aligned_for(const void* p, int dtype) {
     return (reinterpret_cast<uintptr_t>(p) & (dtype == CSPN_F16 ? 7 : 15)) == 0;
 }
 
+// stride 2 x 2, dilation 1, K in {3, 5}, padding K / 2, whole octets, 16-byte aligned bases: the register / DPP kernels of
+// pac_conv2d_s2.hip (no LDS staging, no tile quantisation)
+bool s2_fast(const ConvArgs& a, const void* p0, const void* p1, const void* p2) {
+    if (a.force_scalar || a.transposed) return false;
+    if (!cspn_detail::pac_s2_geometry(a.kh, a.kw, a.sh, a.sw, a.ph, a.pw, a.dh, a.dw, a.W)) return false;
+    if ((size_t)a.H * a.W >= ((size_t)1 << 31)) return false;
+    return ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+}
+cspn_detail::PacS2Args s2_args(const ConvArgs& a) {
+    cspn_detail::PacS2Args r{};
+    r.B = a.B; r.C = a.C; r.CK = a.CK; r.H = a.H; r.W = a.W; r.Ho = a.Ho; r.Wo = a.Wo; r.WQ = a.Wo / 4;
+    r.cchunk = a.C;
+    return r;
+}
+
 bool tiled_geometry(const ConvArgs& a) {
     if ((size_t)a.H * a.W >= ((size_t)1 << 31)) return false;      // the tiled kernels keep plane offsets in int
     return a.kh == a.kw && (a.kh == 3 || a.kh == 5 || a.kh == 7) && a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1;
@@ -1301,6 +1316,8 @@ int launch_tiled_k(const T* src, const T* kern, T* dst, const ConvArgs& a, int d
 
 template <typename T>
 int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, hipStream_t st) {
+    if (s2_fast(a, in, kern, out))
+        return cspn_detail::pac_s2_forward(in, kern, out, std::is_same<T, __half>::value ? CSPN_F16 : CSPN_F32, a.kh, s2_args(a), st);
     if (tiled_geometry(a) && !a.force_scalar) {
         const T* i = static_cast<const T*>(in);
         const T* k = static_cast<const T*>(kern);
@@ -1421,6 +1438,8 @@ int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
 
 template <typename T>
 int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStream_t st) {
+    if (s2_fast(a, gout, in, gk))
+        return cspn_detail::pac_s2_grad_kernel(gout, in, gk, std::is_same<T, __half>::value ? CSPN_F16 : CSPN_F32, a.kh, s2_args(a), st);
     if (tiled_geometry(a) && !a.force_scalar) {
         const T* g = static_cast<const T*>(gout);
         const T* i = static_cast<const T*>(in);
@@ -1478,6 +1497,8 @@ int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStr
 
 template <typename T>
 int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int in_vec, hipStream_t st) {
+    if (s2_fast(a, gout, kern, gin))
+        return cspn_detail::pac_s2_grad_input(gout, kern, gin, std::is_same<T, __half>::value ? CSPN_F16 : CSPN_F32, a.kh, s2_args(a), st);
     if (tiled_geometry(a) && !a.force_scalar && (size_t)a.Ho * a.Wo < ((size_t)1 << 31))
         return launch_tiled_k<T, true>(static_cast<const T*>(gout), static_cast<const T*>(kern), static_cast<T*>(gin), a,
                                        in_vec, st);

@@ -165,6 +165,67 @@ def test_fuzz_tiled_geometry_both_kernels(seed):
         assert nmax(gk, wgk) <= tol, (tag, scalar)
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzz_stride2_register_kernels_and_generic(seed):
+    """Stride 2, dilation 1, K in {3, 5}, padding K / 2, W % 8 == 0 takes the register / DPP kernels of pac_conv2d_s2.hip (forward and
+    both gradients); cspn_pac_force_generic(1) forces the generic ones.  Both against the oracle: odd and even H (the last input
+    row pair is half empty), H = 1, one octet per row, rows wider than a wavefront (the first / last lane of a wavefront patches
+    its fringe with scalar loads), ragged channel batches, shared and per-channel kernels, fp16."""
+    rng = np.random.default_rng(5000 + seed)
+    K = (3, 5)[seed % 2]
+    P = K // 2
+    H = int(rng.integers(1, 40)) if seed % 8 else (1, 2, 3, 5)[(seed // 8) % 4]
+    W = 8 * int(rng.integers(1, 12))
+    if seed % 5 == 0:
+        W = 8 * int(rng.integers(65, 160))                  # more than 64 octets per row: wave boundaries inside a row
+        H = int(rng.integers(1, 9))
+    B, C = int(rng.integers(1, 3)), int(rng.integers(1, 10))
+    CK = C if (seed // 2) % 2 else 1
+    dt = torch.float16 if seed % 4 == 3 else torch.float32
+    Ho, Wo = porc.out_size((H, W), K, 2, P, 1)
+    assert Wo == W // 2 and Ho == (H + 1) // 2
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kern = (rng.standard_normal((B, CK, K, K, Ho, Wo)) * 0.3).astype(np.float32)
+    cot = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    if dt == torch.float16:
+        x, kern, cot = (v.astype(np.float16).astype(np.float32) for v in (x, kern, cot))
+    want = porc.pac_conv2d_forward(x, kern, K, 2, P, 1, dtype=np.float64)
+    wgi, wgk = porc.pac_conv2d_backward(x, kern, cot, K, 2, P, 1)
+    tol = 2e-3 if dt == torch.float16 else TOL
+    tag = (B, C, CK, H, W, K, str(dt))
+    for scalar in (0, 1):
+        with force_generic(scalar):
+            out, gi, gk = run_all(x, kern, cot, K, 2, P, 1, dt)
+        assert nmax(out, want) <= tol, (tag, scalar)
+        assert nmax(gi, wgi) <= tol, (tag, scalar)
+        assert nmax(gk, wgk) <= tol, (tag, scalar)
+
+
+@pytest.mark.parametrize("C,CK,K,dt", [(32, 1, 3, torch.float32), (9, 9, 3, torch.float32), (16, 1, 5, torch.float32),
+                                       (6, 6, 5, torch.float32), (12, 1, 3, torch.float16)])
+def test_stride2_full_frame_register_kernels_equal_generic(C, CK, K, dt):
+    """NYU- and KITTI-size frames at stride 2 (many workgroups, channel chunks over blockIdx.y, the wavefront-split channel sum of
+    the shared dL/dkernel): the register kernels against the generic ones on the same tensors."""
+    for B, H, W in ((2, 228, 304), (1, 127, 1216)):
+        torch.manual_seed(21)
+        P = K // 2
+        Ho, Wo = pac.output_size((H, W), K, 2, P, 1)
+        x = torch.randn(B, C, H, W, device=DEV).to(dt).requires_grad_(True)
+        k = (torch.randn(B, CK, K, K, Ho, Wo, device=DEV) * 0.3).to(dt).requires_grad_(True)
+        g = torch.randn(B, C, Ho, Wo, device=DEV).to(dt)
+        res = []
+        for scalar in (0, 1):
+            x.grad = k.grad = None
+            with force_generic(scalar):
+                out = pac.conv2d(x, k, K, 2, P, 1)
+                out.backward(g)
+            res.append((out.detach().float(), x.grad.float().clone(), k.grad.float().clone()))
+        tol = 2e-3 if dt == torch.float16 else 2e-6
+        for got, want in zip(*res):
+            err = float((got - want).abs().max() / want.abs().max())
+            assert err <= tol, (C, CK, K, str(dt), H, W, err)
+
+
 @pytest.mark.parametrize("seed", range(36))
 def test_fuzz_unit_stride_dilated_and_rectangular_windows(seed):
     """Unit stride with dilation / non-square / even windows takes the any-geometry LDS-tiled kernels — forward, dL/dinput
@@ -288,7 +349,7 @@ def test_linearity_and_adjointness_at_full_size():
     assert torch.equal(o2, 2.0 * out.detach())              # scaling by 2 is exact in binary floating point
 
 
-@pytest.mark.parametrize("C,CK,K,s,p,d", [(16, 1, 5, 1, 2, 1), (8, 8, 3, 1, 1, 1), (6, 1, 7, 1, 3, 1), (8, 1, 3, 2, 1, 1),
+@pytest.mark.parametrize("C,CK,K,s,p,d", [(16, 1, 5, 1, 2, 1), (8, 8, 3, 1, 1, 1), (6, 1, 7, 1, 3, 1), (8, 1, 3, 2, 1, 1), (5, 5, 5, 2, 2, 1),
                                           (8, 1, 3, 1, 2, 2), (5, 5, (3, 2), 1, (1, 0), (1, 3))])
 def test_full_frame_against_the_unfold_formulation(C, CK, K, s, p, d):
     """NYU-size frames, many tiles and channel batches: forward and both gradients against the reference's own

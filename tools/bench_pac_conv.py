@@ -32,6 +32,9 @@ CASES = [   # name, B, C, CK, H, W, K, stride, pad, dil, dtype
     ("c64_k5_shared", 8, 64, 1, 228, 304, 5, 1, 2, 1, torch.float32),
     ("c64_k3_perch", 8, 64, 64, 228, 304, 3, 1, 1, 1, torch.float32),
     ("c32_k3_stride2", 8, 32, 1, 228, 304, 3, 2, 1, 1, torch.float32),
+    ("c32_k5_stride2", 8, 32, 1, 228, 304, 5, 2, 2, 1, torch.float32),
+    ("c32_k3_stride2_perch", 8, 32, 32, 228, 304, 3, 2, 1, 1, torch.float32),
+    ("c32_k3_stride2_f16", 8, 32, 1, 228, 304, 3, 2, 1, 1, torch.float16),
     ("c32_k3_dil2", 8, 32, 1, 228, 304, 3, 1, 2, 2, torch.float32),
     ("c16_k7_shared", 8, 16, 1, 228, 304, 7, 1, 3, 1, torch.float32),
 ]
