@@ -171,6 +171,12 @@ template <> struct TailRaw<__half> {
     static __device__ __forceinline__ S zero() { return 0u; }
 };
 
+#ifndef CSPN_TAIL_REBUILD_W
+#define CSPN_TAIL_REBUILD_W 1      // 3x3 epilogue: rebuild w_j from the guidance quads + S instead of reading the tap volume
+#endif
+#ifndef CSPN_TAIL_PROBE
+#define CSPN_TAIL_PROBE 0          // developer A/B: 1 = no scatter epilogue (stream + epilogue loads only), 2 = no stream loop
+#endif
 template <int K, typename DT, typename WT, int VARIANT>
 __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
     constexpr int R = K / 2;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
 #endif
     constexpr int UNR = (K == 3) ? CSPN_TAIL_UNR3 : (K == 5 ? 2 : 1);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t0 = 0; t0 < T; t0 += UNR) {
+    for (int t0 = 0; t0 < (CSPN_TAIL_PROBE == 2 ? 0 : T); t0 += UNR) {
         typedef TailRaw<DT> RW;
         float4 Gq[UNR];
         typename RW::Q midq[UNR][2 * R + 1];
@@ -327,11 +333,62 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
                                                  sm[j][2] * (acc[j][2] - dot[2]), sm[j][3] * (acc[j][3] - dot[3])));
     } else {
         static_assert(VARIANT != 1 || K == 3, "guidance epilogue is the 3x3 variant");
-        const WT* w8 = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(8, HW);
         const WT* g = static_cast<const WT*>(a.guidance) + (size_t)b * a.g_bs;
         WT* gg = static_cast<WT*>(a.gout) + (size_t)b * a.g_bs;
+        const float4 Sv = ld4(a.S + off);
+        const float S4[4] = {Sv.x, Sv.y, Sv.z, Sv.w};
+#if CSPN_TAIL_REBUILD_W
+        // w_j[p] = |g_{7-j}[p + off_j]| / S[p] is REBUILT from the guidance quads this epilogue loads anyway (for the signs of the
+        // scatter targets) instead of being read back from the forward's tap volume: the aligned quad of channel 7-j on row
+        // y + dy_j, shifted by dx_j with one DPP move (strip-end lanes patch with the scalar they load for their extra store).
+        // Same recipe as the forward (div8_shared_reciprocal: |g| * refined 1/S), so fp32 taps come out bit-identical; 53 MB
+        // less to read per backward at config 2.
+        float gq[8][4], gl[8], gr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int dy = lin / 3 - 1, dx = lin % 3 - 1;
+            const int ty = y + dy;
+            const bool tok = ty >= 0 && ty < H;
+            const size_t o = (size_t)(7 - j) * a.g_cs + (size_t)(tok ? ty : 0) * W + x;
+            const float4 q4 = ld4(g + o);
+            gq[j][0] = tok ? q4.x : 0.f; gq[j][1] = tok ? q4.y : 0.f; gq[j][2] = tok ? q4.z : 0.f; gq[j][3] = tok ? q4.w : 0.f;
+            gl[j] = gr[j] = 0.f;
+            if (dx > 0 && lane == 63 && qx < WQ - 1 && tok) gr[j] = ld1(g + o + 4);
+            if (dx < 0 && lane == 0 && qx > 0 && tok) gl[j] = ld1(g + o - 1);
+        }
+#endif
+        float rS[4];          // 1/S by the forward's recipe (rcp + one Newton step): 4 reciprocals instead of 32 divisions
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r = __builtin_amdgcn_rcpf(S4[e]);
+            rS[e] = fmaf(fmaf(-S4[e], r, 1.0f), r, r);
+        }
         float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#if CSPN_TAIL_REBUILD_W
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lin = j < 4 ? j : j + 1;
+            const int dx = lin % 3 - 1;
+            float ax[4];
+            if (dx == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ax[e] = gq[j][e];
+            } else if (dx > 0) {
+                float nx = dpp_from_next_lane(gq[j][0]);
+                if (fix_right) nx = gr[j];                       // 0 at the row end: the gate beyond the image is the zero padding
+                ax[0] = gq[j][1]; ax[1] = gq[j][2]; ax[2] = gq[j][3]; ax[3] = nx;
+            } else {
+                float pv = dpp_from_prev_lane(gq[j][3]);
+                if (fix_left) pv = gl[j];
+                ax[0] = pv; ax[1] = gq[j][0]; ax[2] = gq[j][1]; ax[3] = gq[j][2];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot[e] = fmaf(acc[j][e], fabsf(ax[e]) * rS[e], dot[e]);
+        }
+#else
         {
+            const WT* w8 = static_cast<const WT*>(a.w) + (size_t)b * Taps<WT>::image_elems(8, HW);
             float w4[8][4];
             load_taps_quad<8>(w8, (size_t)y * W + x, HW, true, w4);
 #pragma unroll
@@ -339,14 +396,11 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dot[e] = fmaf(acc[j][e], w4[j][e], dot[e]);
         }
-        const float4 Sv = ld4(a.S + off);
-        const float S4[4] = {Sv.x, Sv.y, Sv.z, Sv.w};
-        float rS[4];          // 1/S by the forward's recipe (rcp + one Newton step): 4 reciprocals instead of 32 divisions
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float r = __builtin_amdgcn_rcpf(S4[e]);
-            rS[e] = fmaf(fmaf(-S4[e], r, 1.0f), r, r);
-        }
+#endif
+#if CSPN_TAIL_PROBE == 1
+        if (dot[0] == 12345.678f) st4(gg + (size_t)y * W + x, make_float4(dot[0], dot[1], dot[2], dot[3]));      // stream + loads only
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int lin = j < 4 ? j : j + 1;
@@ -364,7 +418,12 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
             const float from_next = dpp_from_next_lane(gA[0]);
             if (ty >= 0 && ty < H) {
                 const size_t o = cplane + (size_t)ty * W + x;
+#if CSPN_TAIL_REBUILD_W
+                const float4 gs = sgn4(make_float4(gq[j][0], gq[j][1], gq[j][2], gq[j][3]));
+                const float gs_r = sgnf(gr[j]), gs_l = sgnf(gl[j]);
+#else
                 const float4 gs = sgn4(ld4(g + o));
+#endif
                 if (dx == 0) {
                     st4(gg + o, make_float4(gs.x * gA[0], gs.y * gA[1], gs.z * gA[2], gs.w * gA[3]));
                 } else if (dx > 0) {
@@ -374,7 +433,11 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
                     } else {
                         st4(gg + o, make_float4(gs.x * v0, gs.y * gA[0], gs.z * gA[1], gs.w * gA[2]));
                     }
+#if CSPN_TAIL_REBUILD_W
+                    if (lane == 63 && qx < WQ - 1) st1(gg + o + 4, gs_r * gA[3]);
+#else
                     if (lane == 63 && qx < WQ - 1) st1(gg + o + 4, sgnf(ld1(g + o + 4)) * gA[3]);
+#endif
                 } else {
                     const float v3 = (qx == WQ - 1) ? 0.f : from_next;         // column W-1 has no source
                     if (lane == 63 && qx < WQ - 1) {
@@ -382,7 +445,11 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
                     } else {
                         st4(gg + o, make_float4(gs.x * gA[1], gs.y * gA[2], gs.z * gA[3], gs.w * v3));
                     }
+#if CSPN_TAIL_REBUILD_W
+                    if (lane == 0 && qx > 0) st1(gg + o - 1, gs_l * gA[0]);
+#else
                     if (lane == 0 && qx > 0) st1(gg + o - 1, sgnf(ld1(g + o - 1)) * gA[0]);
+#endif
                 }
             }
             // rows of this plane that no source row reaches: row 0 (dy=+1) / row H-1 (dy=-1)

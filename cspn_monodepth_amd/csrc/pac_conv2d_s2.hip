@@ -396,7 +396,7 @@ int forward_k(const void* in_, const void* kern_, void* out_, PacS2Args a, hipSt
     T* out = static_cast<T*>(out_);
     constexpr int CB = K == 3 ? 2 : 1;
     const int gx = ceil_div(a.Ho * a.WQ, 256);
-    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 2048);
+    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 1024);
     const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
     if (a.CK == 1) pac_s2_fwd<T, K, true, CB><<<grid, block, 0, st>>>(in, kern, out, a);
     else pac_s2_fwd<T, K, false, CB><<<grid, block, 0, st>>>(in, kern, out, a);
@@ -411,7 +411,7 @@ int grad_input_k(const void* gout_, const void* kern_, void* gin_, PacS2Args a, 
     T* gin = static_cast<T*>(gin_);
     constexpr int CB = K == 3 ? 2 : 1;
     const int gx = ceil_div(a.Ho * a.WQ, 256);
-    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 2048);
+    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 1024);
     const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
     if (a.CK == 1) pac_s2_gi<T, K, true, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
     else pac_s2_gi<T, K, false, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
@@ -432,7 +432,7 @@ int grad_kernel_k(const void* gout_, const void* in_, void* gk_, PacS2Args a, hi
     } else {
         constexpr int CB = K == 3 ? 2 : 1;
         const int gx = ceil_div(a.Ho * a.WQ, 256);
-        a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 2048);
+        a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 1024);
         const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
         pac_s2_gk_perch<T, K, CB><<<grid, block, 0, st>>>(gout, in, gk, a);
     }
