@@ -20,14 +20,14 @@ HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(CSRC, "cspnk_help
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 8          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 9          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "cspn_abi_version", "cspn_last_error", "cspn_plan_resolve", "cspn3_prepare", "cspn_pac_prepare",
     "cspn_propagate_workspace_bytes", "cspn_propagate", "cspn_propagate_scored", "cspn_propagate_transposed", "cspn3_propagate_from_guidance",
-    "cspn_transpose_weights", "cspn3_resident_plan", "cspn3_resident_workspace_bytes", "cspn3_forward_resident", "cspn3_transposed_resident",
+    "cspn_transpose_weights", "cspn3_resident_plan", "cspn3_resident_workspace_bytes", "cspn3_forward_resident", "cspn3_transposed_resident", "cspn3_transposed_resident_guidance",
     "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident", "cspnk_forward_resident_history", "cspnk_transposed_resident",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
@@ -160,6 +160,8 @@ def _declare(lib):
                                            ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspn3_transposed_resident.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, ci,
                                               ctypes.POINTER(cspn_resident_plan), vp]
+    lib.cspn3_transposed_resident_guidance.argtypes = [vp, cl, cl, vp, vp, vp, vp, vp, ctypes.c_uint, vp, ci, ci, ci, ci, ci, ci,
+                                                       ctypes.POINTER(cspn_resident_plan), vp]
     lib.cspnk_resident_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(cspn_resident_plan)]
     lib.cspnk_resident_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.cspnk_resident_workspace_bytes.restype = cs

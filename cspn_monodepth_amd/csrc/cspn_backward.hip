@@ -703,7 +703,11 @@ bool tail5_split_enabled() {
 template <int K, typename DT, typename WT>
 int launch_tail(const TailArgs& a, int variant, hipStream_t st) {
     const size_t nquads = (size_t)a.B * a.H * (a.W / 4);
+#ifndef CSPN_TAIL_BLOCK
+#define CSPN_TAIL_BLOCK 256
+#endif
     const int grid = (int)((nquads + 255) / 256);
+    const int grid3 = (int)((nquads + CSPN_TAIL_BLOCK - 1) / CSPN_TAIL_BLOCK);
     if constexpr (K == 5) {
         if ((variant == 0 || variant == 2) && tail5_split_enabled()) {
             const int grid5 = (int)((nquads + 127) / 128);
@@ -715,7 +719,7 @@ int launch_tail(const TailArgs& a, int variant, hipStream_t st) {
     }
     if (variant == 0) hipLaunchKernelGGL((cspn_grad_tail<K, DT, WT, 0>), dim3(grid), dim3(256), 0, st, a);
     else if (variant == 2) hipLaunchKernelGGL((cspn_grad_tail<K, DT, WT, 2>), dim3(grid), dim3(256), 0, st, a);
-    else if constexpr (K == 3) hipLaunchKernelGGL((cspn_grad_tail<3, DT, WT, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if constexpr (K == 3) hipLaunchKernelGGL((cspn_grad_tail<3, DT, WT, 1>), dim3(grid3), dim3(CSPN_TAIL_BLOCK), 0, st, a);
     else return fail("backward tail variant %d unsupported for K=%d", variant, K);
     HIP_OK(hipGetLastError());
     return 1;
@@ -821,8 +825,11 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
 int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
                         const void* guidance, long bs, long cs, int C, const void* w8, const float* s,
                         void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T, cspn_stream_t stream) {
-    if (!d0 || !g_T || !guidance || !w8 || !s || !grad_guidance || !gd0 || (T > 1 && !dhist) || (T > 0 && !ghist))
+    if (!d0 || !g_T || !guidance || !s || !grad_guidance || !gd0 || (T > 1 && !dhist) || (T > 0 && !ghist))
         return fail("cspn3_backward_tail: NULL pointer");
+#if !CSPN_TAIL_REBUILD_W
+    if (!w8) return fail("cspn3_backward_tail: this build reads the tap volume (CSPN_TAIL_REBUILD_W=0): w8 is required");
+#endif
     TailArgs a{};
     a.d0 = d0; a.dhist = dhist; a.g_T = g_T; a.ghist = ghist; a.sparse = sparse; a.w = w8; a.S = s; a.guidance = guidance;
     a.gout = grad_guidance; a.gd0 = gd0; a.g_bs = bs; a.g_cs = cs; a.B = B; a.H = H; a.W = W; a.T = T; a.C = C;

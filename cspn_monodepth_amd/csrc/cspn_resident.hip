@@ -56,6 +56,7 @@ struct ResArgs {
     float* hist;             // MODE 2: [T][B,H,W] receives the state after every step (d_1 .. d_T), `out` is unused
     float* w_out;            // MODE 2: [B,8,H,W] receives the normalised weights (the backward streams them)
     float* s_out;            // MODE 2: [B,H,W] receives the normaliser S (the backward's quotient rule needs it)
+    const float* s_in;       // MODE 4: [B,H,W] the normaliser S the training forward published (a.g is the raw guidance)
     const float* target;     // MODE 1: [B,H,W]
     double* macc;
     int nslots;
@@ -134,7 +135,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // tap j = w_{7-j}[p + off_j], gathered from the forward tap volume [B,8,H,W] (a.g) exactly like channel 7-j of the
     // guidance is gathered for the forward — minus |.| and the normalisation.  BLEND then means PREMASK: the state that
     // travels (LDS, exchange planes) is (1-m) G, the history planes receive G itself.  d0 is G_T = dL/dout.
-    constexpr bool SCORE = MODE == 1, TRANS = MODE == 3, HIST = MODE == 2 || TRANS;
+    // MODE 4: the same reverse sweep with the transposed taps REBUILT from the raw guidance and the published normaliser instead
+    // of gathered from a tap volume:  w_{7-j}[p + off_j] = |g_j[p]| / S[p + off_j]  — the guidance channel j at the quad itself
+    // (no shifted gather at all), times the forward's refined reciprocal of S at the 3 x 3 neighbours (NQ + 2 aligned row quads
+    // of ONE plane per thread, neighbours by DPP, strip ends by scalars).  The training forward then publishes S only: the
+    // 53 MB volume of config 2 is neither written nor read (the tail rebuilds its w_j the same way, cspn_backward.hip).
+    constexpr bool SCORE = MODE == 1, TRANSG = MODE == 4, TRANS = MODE == 3 || TRANSG, HIST = MODE == 2 || TRANS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int wg_bad;
 
@@ -256,6 +262,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // scalars are requested right behind quad i's planes and the arithmetic below can start on quad 0 while quads 1.. stream.)
     float edge[NQ][6];                     // [0..2]: column xq-1 of the dx<0 taps (j = 0,3,5); [3..5]: column xq+4 of the dx>0 taps (j = 2,4,7)
     const unsigned ucs = (unsigned)a.g_cs;
+    // MODE 4: rows yq0-1 .. yq0+NQ of S, requested in front of the guidance (in-order return: the reciprocals are formed while
+    // the guidance streams); [m][0..3] the aligned quad, [m][4] / [m][5] columns xq-1 / xq+4 for the strip-end lanes
+    float srow[TRANSG ? NQ + 2 : 1][6];
+    if constexpr (TRANSG) {
+        const float* __restrict__ sq = uniform_ptr(a.s_in + (size_t)b * HW);
+#pragma unroll
+        for (int m = 0; m < NQ + 2; ++m) {
+            const int ys = yq0 - 1 + m;
+            const bool v = x_in && ys >= 0 && ys < H;
+            const unsigned o = v ? (unsigned)(ys * W + xq) : 0u;
+            const float4 q4 = ld4(at32(sq, o));
+            srow[m][0] = q4.x; srow[m][1] = q4.y; srow[m][2] = q4.z; srow[m][3] = q4.w;
+            srow[m][4] = ld1(at32(sq, (v && fix_left && xq >= 1) ? o - 1u : 0u));
+            srow[m][5] = ld1(at32(sq, (v && fix_right && xq + 4 < a.Wv) ? o + 4u : 0u));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int r = r0 + i, y = yq0 + i;
@@ -273,14 +295,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int lin = j < 4 ? j : j + 1;
-            const int d = PAC ? 1 : lin / 3;                          // PAC: channel j at the quad itself
-            const float4 v = ld4(at32(gq, (unsigned)(PAC ? j : 7 - j) * ucs + orow[d]));
+            const int d = (PAC || TRANSG) ? 1 : lin / 3;              // PAC / MODE 4: channel j at the quad itself
+            const float4 v = ld4(at32(gq, (unsigned)((PAC || TRANSG) ? j : 7 - j) * ucs + orow[d]));
             wreg[i][j][0] = rokv[d] ? v.x : 0.f; wreg[i][j][1] = rokv[d] ? v.y : 0.f;
             wreg[i][j][2] = rokv[d] ? v.z : 0.f; wreg[i][j][3] = rokv[d] ? v.w : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 6; ++t) edge[i][t] = 0.f;
-        if (!PAC && (fix_left || fix_right)) {
+        if (!PAC && !TRANSG && (fix_left || fix_right)) {
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const bool lft = t < 3;
@@ -326,9 +348,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             mraw[i] = ld4(at32(spg, ok ? (unsigned)((yq0 + i) * W + xq) : 0u));
         }
     }
+    if constexpr (TRANSG) {
+        // 1 / S by the forward's recipe (div8_shared_reciprocal), 0 where the neighbour lies outside the (valid) image: in place,
+        // columns xq-1 .. xq+4 of every row end up as srow[m][4], [0..3], [5]
+#pragma unroll
+        for (int m = 0; m < NQ + 2; ++m) {
+            const int ys = yq0 - 1 + m;
+            const bool v = x_in && ys >= 0 && ys < H;
+            auto rcp_fwd = [](float S) -> float {
+                const bool okr = (S <= 0x1p+100f) && (S >= 0x1p-100f || S == 0.f);
+                float r = __builtin_amdgcn_rcpf(S);
+                r = fmaf(fmaf(-S, r, 1.0f), r, r);
+                return okr ? r : 1.0f / S;
+            };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) srow[m][e] = (v && e < nval) ? rcp_fwd(srow[m][e]) : 0.f;
+            const float nl = dpp_from_prev_lane(srow[m][3]), nr = dpp_from_next_lane(srow[m][0]);
+            srow[m][4] = fix_left ? ((v && xq >= 1) ? rcp_fwd(srow[m][4]) : 0.f) : nl;
+            srow[m][5] = fix_right ? ((v && xq + 4 < a.Wv) ? rcp_fwd(srow[m][5]) : 0.f) : nr;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const bool ok = (in_img >> i) & 1u;
+        if constexpr (TRANSG) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int lin = j < 4 ? j : j + 1;
+                const int m = i + lin / 3, dx = lin % 3 - 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = e + dx;
+                    const float rs = c < 0 ? srow[m][4] : (c > 3 ? srow[m][5] : srow[m][c]);
+                    wreg[i][j][e] = (ok && e < nval) ? fabsf(wreg[i][j][e]) * rs : 0.f;
+                }
+            }
+            continue;
+        }
         // does edge[i][t] hold a pixel inside the image?  (recomputed: a bit mask built while the loads are issued is one
         // more live register there)
         auto edge_in = [&](int j, bool lft) -> bool {
@@ -396,7 +452,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
             for (int j = 0; j < NT; ++j) wreg[i][j][e] = (ok && e < nval) ? qv[j] : 0.f;
         }
         if (MODE == 2 && ((interior >> i) & 1u)) {   // publish before the blend is folded in: the backward wants w and S themselves
-            store_taps_quad<NT>(a.w_out + (size_t)b * NT * HW, off, HW, wreg[i]);
+            if (a.w_out) store_taps_quad<NT>(a.w_out + (size_t)b * NT * HW, off, HW, wreg[i]);     // null: S only (the backward rebuilds w)
             st4(at32(uniform_ptr(a.s_out + (size_t)b * HW), off), make_float4(Sq[0], Sq[1], Sq[2], Sq[3]));
         }
     }
@@ -861,11 +917,12 @@ int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream
 
 template <int NQ, int CLEAN>
 int launch_resident_c(const ResArgs& a, int grid, size_t lds, int blend, int mode, hipStream_t st) {
-    if (mode >= 4) {          // softmax-weight (PAC) forms of MODE 0 / 1 / 2
+    if (mode >= 4 && mode <= 6) {          // softmax-weight (PAC) forms of MODE 0 / 1 / 2
         if (mode == 6) return blend ? launch_resident_inst<NQ, 1, 2, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 2, CLEAN, 1>(a, grid, lds, st);
         if (blend) return mode == 5 ? launch_resident_inst<NQ, 1, 1, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 1, 0, CLEAN, 1>(a, grid, lds, st);
         return mode == 5 ? launch_resident_inst<NQ, 0, 1, CLEAN, 1>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 0, CLEAN, 1>(a, grid, lds, st);
     }
+    if (mode == 7) return blend ? launch_resident_inst<NQ, 1, 4, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 4, CLEAN>(a, grid, lds, st);
     if (mode == 3) return blend ? launch_resident_inst<NQ, 1, 3, CLEAN>(a, grid, lds, st) : launch_resident_inst<NQ, 0, 3, CLEAN>(a, grid, lds, st);
     if (blend) {
         if (mode == 2) return launch_resident_inst<NQ, 1, 2, CLEAN>(a, grid, lds, st);
@@ -886,7 +943,7 @@ namespace {
 int resident_launch(const void* guidance, long bs, long cs, const void* d0, const void* sparse, void* out, void* history,
                     void* w8_out, float* s_out, void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid,
                     int T, int blend, const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
-                    cspn_stream_t stream, bool transposed, bool pac = false);
+                    cspn_stream_t stream, bool transposed, bool pac = false, const float* s_in = nullptr);
 }
 
 extern "C" {
@@ -932,6 +989,18 @@ int cspn3_transposed_resident(const void* w8, const float* g_T, const float* spa
                            /*transposed=*/true);
 }
 
+int cspn3_transposed_resident_guidance(const void* guidance, long bs, long cs, const float* S, const float* g_T,
+                                       const float* sparse_f32, float* history, void* work, unsigned seq, unsigned* host_err,
+                                       int B, int H, int W, int W_valid, int T, int premask, const cspn_resident_plan* plan,
+                                       cspn_stream_t stream) {
+    if (!guidance || !S || !g_T || !history) return fail("cspn3_transposed_resident_guidance: bad arguments");
+    if (premask && !sparse_f32) return fail("cspn3_transposed_resident_guidance: premask needs sparse");
+    if (!aligned16(S)) return fail("cspn3_transposed_resident_guidance: S must be 16-byte aligned");
+    return resident_launch(guidance, bs, cs, g_T, premask ? sparse_f32 : nullptr, nullptr, history, nullptr, nullptr, work, seq,
+                           host_err, B, H, W, W_valid, T, premask ? 1 : 0, nullptr, nullptr, 0, plan, stream,
+                           /*transposed=*/true, /*pac=*/false, S);
+}
+
 }  // extern "C"
 
 namespace cspn_detail {
@@ -951,11 +1020,11 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
                     void* history, void* w8_out, float* s_out,
                     void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int W_valid, int T, int blend,
                     const void* target, double* acc, int nslots, const cspn_resident_plan* plan,
-                    cspn_stream_t stream, bool transposed, bool pac) {
+                    cspn_stream_t stream, bool transposed, bool pac, const float* s_in) {
     if (!guidance || !d0 || !work || B <= 0 || H <= 0 || W <= 0 || T < 1 || (!out && !history))
         return fail("cspn3_forward_resident: bad arguments");
-    if (!transposed && history && (!w8_out || (!pac && !s_out) || target || acc || !aligned16(history) || !aligned16(w8_out) || (s_out && !aligned16(s_out))))
-        return fail("cspn3_forward_resident: the training form (history) needs w8_out and s_out, 16-byte aligned, and no scoring");
+    if (!transposed && history && ((pac && !w8_out) || (!pac && !s_out) || target || acc || !aligned16(history) || (w8_out && !aligned16(w8_out)) || (s_out && !aligned16(s_out))))
+        return fail("cspn3_forward_resident: the training form (history) needs s_out (w8_out is optional: null publishes S only), 16-byte aligned, and no scoring");
     if (!history && (w8_out || s_out)) return fail("cspn3_forward_resident: w8_out / s_out are outputs of the training form (history)");
     if (transposed && !aligned16(history)) return fail("cspn3_transposed_resident: history must be 16-byte aligned");
     if (blend != CSPN_BLEND_NONE && blend != CSPN_BLEND_SPARSE) return fail("cspn3_forward_resident: blend %d", blend);
@@ -1011,7 +1080,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     a.host_err = host_err;
     a.hist = static_cast<float*>(history); a.w_out = static_cast<float*>(w8_out); a.s_out = s_out;
     if (pac && transposed) return fail("cspn3_forward_resident: the softmax-weight form has no transposed sweep (use cspn3_transposed_resident on the volume)");
-    const int mode = transposed ? 3 : (history ? 2 : (acc ? 1 : 0)) + (pac ? 4 : 0);
+    const int mode = transposed ? (s_in ? 7 : 3) : (history ? 2 : (acc ? 1 : 0)) + (pac ? 4 : 0);
+    a.s_in = s_in;
     a.seq = seq;
     a.target = static_cast<const float*>(target); a.macc = acc; a.nslots = nslots;
     a.B = B; a.H = H; a.W = W; a.Wv = (W_valid > 0 && W_valid < W) ? W_valid : W; a.T = T; a.S = g.S;

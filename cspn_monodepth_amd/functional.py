@@ -924,6 +924,25 @@ def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
     return ghist
 
 
+def transposed_resident_guidance(guidance, S, g_T, sparse_f32, T, valid_w=0):
+    """The same reverse sweep without a tap volume: the transposed taps |g_j[p]| / S[p + off_j] are rebuilt from the raw guidance
+    and the normaliser S the training forward published (include/cspn_hip.h cspn3_transposed_resident_guidance)."""
+    dev = _require_device(guidance, S, g_T, sparse_f32)
+    B, H, W = g_T.shape
+    L = _lib.lib()
+    ghist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
+    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1])
+
+    def launch(work, seq, host_err_ptr, stream_ptr):
+        return L.cspn3_transposed_resident_guidance(_p(guidance), guidance.stride(0), guidance.stride(1), _p(S), _p(g_T), _p(sparse_f32),
+                                                    _p(ghist), _p(work), seq, host_err_ptr, B, H, W, int(valid_w), int(T),
+                                                    int(sparse_f32 is not None), None if rp is None else ctypes.byref(rp), stream_ptr)
+
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True)
+    _lib.check(ok, "cspn3_transposed_resident_guidance")
+    return ghist
+
+
 def pac_transposed_resident(wk, g_T, sparse, T):
     """K = 5 reverse sweep on the forward's fp16 tap volume as weight-resident launches.  Returns (G_T as fp32 [B,H,W], ghist
     [T,B,H,W] f32 = G_{T-1} .. G_0).  The transposed taps are gathered once per launch and stay packed in registers; no
@@ -952,11 +971,12 @@ def pac_transposed_resident(wk, g_T, sparse, T):
 
 
 def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None,
-                     keep_history=False):
+                     keep_history=False, publish_weights=True):
     """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it.
 
     keep_history=True is the training forward: returns (d_T [view of history[T-1]], history [T,B,H,W], w8 [B,8,H,W],
-    S [B,H,W]) — the launch writes every step's state to its history plane and publishes the weights and S once."""
+    S [B,H,W]) — the launch writes every step's state to its history plane and publishes the weights and S once;
+    publish_weights=False publishes S only (w8 is None): the backward rebuilds the taps from guidance and S."""
     dev = guidance.device
     if not guidance.is_cuda:
         _require_device(guidance, d0, sparse)          # raises
@@ -965,7 +985,7 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
     hist = w8 = S_out = out = None
     if keep_history:
         hist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
-        w8 = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
+        w8 = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev) if publish_weights else None
         S_out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     else:
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
@@ -1155,13 +1175,28 @@ def transpose_weights(w, K, H, W):
     return wT
 
 
-def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0):
+def _reverse_sweep(w, K, T, sparse, grad_out, plan, valid_w=0, guidance_S=None):
     """G_T = dL/dout, G_t = stencil^T((1-m) G_{t+1}): the forward kernel on the transposed weights.
+    w may be None for K = 3 when guidance_S = (guidance, S) is given (the forward published S only): the weight-resident
+    sweep rebuilds the taps from them; any other schedule first rebuilds the volume with cspn3_prepare (the same bits).
     Returns (g_T [B,H,W] f32 — grad_out itself, not a copy, when it is fp32 —, ghist [T,B,H,W] f32 in backward order:
     ghist[s] = G_{T-1-s}; None when T == 0)."""
-    dev = w.device
+    dev = grad_out.device
     B, H, W = grad_out.shape[0], grad_out.shape[-2], grad_out.shape[-1]
     g_T = grad_out.reshape(B, H, W)
+    if w is None:
+        gd, S = guidance_S
+        sp32 = None if sparse is None else sparse.float()
+        g32 = g_T.float()
+        if g32.data_ptr() % 16:
+            g32 = g32.clone()
+        if (K == 3 and T > 0 and gd.dtype == torch.float32 and W % 4 == 0 and gd.data_ptr() % 16 == 0 and gd.stride(0) % 4 == 0
+                and gd.stride(1) % 4 == 0 and gd.stride(1) < (1 << 27) and gd.stride(3) == 1 and gd.stride(2) == W
+                and (sp32 is None or sp32.data_ptr() % 16 == 0) and _RESIDENT_MODE != "off" and plan is None
+                and _DEFAULT_PLANS.get(3) is None and H * W < (1 << 27) and not torch.cuda.is_current_stream_capturing()
+                and _resident_plan_cached(B, H, W, int(T), int(sp32 is not None), dev)[0] is not None):
+            return g32, transposed_resident_guidance(gd, S, g32, sp32, T, valid_w)
+        w = cspn3_prepare(gd, want_s=False, valid_w=valid_w)[0]
     if g_T.data_ptr() % 16:
         g_T = g_T.clone()
     ghist = None
@@ -1277,7 +1312,10 @@ class CSPN3Function(torch.autograd.Function):
         if need_grad and prop_time > 0 and resident_supported(guidance, d0, sp, prop_time, plan) is not None:
             # training, weight-resident: one launch writes the T depth planes and publishes the weights + S for the backward
             g = guidance
-            out, hist, w8, S = forward_resident(g, d0, sp, prop_time, blend, valid_w=valid_w, keep_history=True)
+            # (S only: the reverse sweep and the tail rebuild the taps from guidance + S — no 8-plane volume to write or read;
+            #  CSPN_TRAIN_VOLUME=1 keeps it, for A/B runs)
+            out, hist, w8, S = forward_resident(g, d0, sp, prop_time, blend, valid_w=valid_w, keep_history=True,
+                                                publish_weights=os.environ.get("CSPN_TRAIN_VOLUME", "0") == "1")
         elif need_grad and _FROM_GUIDANCE and prop_time > 0 and from_guidance_supported(guidance, d0, sp, plan):
             # training: the first launch derives the weights, publishes them and S for the backward, and the loop keeps
             # the T depth planes — one pass over the guidance instead of a prepare pass + a re-read of the volume
@@ -1299,16 +1337,18 @@ class CSPN3Function(torch.autograd.Function):
         B, C, H, W = g.shape
         T = ctx.prop_time
         L = _lib.lib()
-        g_T, ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w)
+        g_T, ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w, guidance_S=(g, S))
         _check_resident_at_end_of_backward(g.device)
         gg = torch.empty_like(g)
-        if _tail_vector_ok(W, g, w8, S, d0, sp, hist, gg) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
+        if _tail_vector_ok(W, g, S, d0, sp, hist, gg) and (w8 is None or w8.data_ptr() % 16 == 0) and g.stride(0) % 4 == 0 and g.stride(1) % 4 == 0:
             gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)
             with _device_guard(g.device):
                 ok = L.cspn3_backward_tail(_p(d0), _p(hist), _p(g_T), _p(ghist), _p(sp), _p(g), g.stride(0), g.stride(1), C,
                                            _p(w8), _p(S), _p(gg), _p(gd0), _dt(g), B, H, W, T, _stream(g.device))
             _lib.check(ok, "cspn3_backward_tail")
         else:
+            if w8 is None:
+                w8 = cspn3_prepare(g, want_s=False, valid_w=ctx.valid_w)[0]
             gw, gd0 = _grad_weights(w8, 3, T, d0, hist, sp, g_T, ghist)
             with _device_guard(g.device):
                 ok = L.cspn3_grad_guidance(_p(g), _dt(g), g.stride(0), g.stride(1), C, _p(w8), _dt(w8),

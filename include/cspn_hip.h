@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 8
+#define CSPN_ABI_VERSION 9
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -189,9 +189,12 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
  * the three-call form above).  One pass over the histories accumulates dL/dw in registers and applies the
  * guidance / softmax epilogue there, so dL/dw never goes to HBM:
  *   cspn3_backward_tail    = cspn_grad_weights + cspn3_grad_guidance   (all tensors of one dtype)
- *   cspn_pac_backward_tail = cspn_grad_weights + cspn_pac_grad_guided */
+ *   cspn_pac_backward_tail = cspn_grad_weights + cspn_pac_grad_guided
+ * cspn3_backward_tail does not read the tap volume (ABI 9): w_j[p] = |g_{7-j}[p + off_j]| / S[p] is rebuilt from the guidance
+ * quads its epilogue loads anyway and from s, by the forward's recipe (bit-identical fp32 taps); w8_or_null is accepted for
+ * source compatibility and ignored. */
 int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
-                        const void* guidance, long g_batch_stride, long g_chan_stride, int C, const void* w8,
+                        const void* guidance, long g_batch_stride, long g_chan_stride, int C, const void* w8_or_null,
                         const float* s, void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T,
                         cspn_stream_t stream);
 /* gd0_dtype: CSPN_F32, or CSPN_F16 — dL/dx0 rounded to half where it is produced (what a cast of the fp32 plane gives). */
@@ -280,7 +283,9 @@ int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_re
 size_t cspn3_resident_workspace_bytes(int B, int H, int W);
 /* Training form: history != NULL ([T,B,H,W] f32, receives d_1..d_T; `out` may be NULL) together with w8_out ([B,8,H,W])
  * and s_out ([B,H,W]): the launch also publishes the normalised weights and the normaliser S once — exactly what
- * cspn3_propagate_from_guidance hands the backward (cspn_propagate_transposed, cspn3_backward_tail).  No scoring then. */
+ * cspn3_propagate_from_guidance hands the backward (cspn_propagate_transposed, cspn3_backward_tail).  No scoring then.
+ * w8_out may be NULL (ABI 9): only S is published — enough for cspn3_transposed_resident_guidance + cspn3_backward_tail, which
+ * rebuild the taps from guidance and S; the 8-plane volume (53 MB at config 2) is then neither written nor read. */
 int cspn3_forward_resident(const void* guidance, long g_batch_stride, long g_chan_stride, const void* d0,
                            const void* sparse_or_null, void* out, void* history_or_null, void* w8_out_or_null,
                            float* s_out_or_null, void* work, unsigned seq, unsigned* host_err_or_null,
@@ -295,6 +300,15 @@ int cspn3_forward_resident(const void* guidance, long g_batch_stride, long g_cha
 int cspn3_transposed_resident(const void* w8, const float* g_T, const float* sparse_f32_or_null, float* history, void* work,
                               unsigned seq, unsigned* host_err_or_null, int B, int H, int W, int W_valid, int T, int premask,
                               const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
+/* The same reverse sweep without a tap volume (ABI 9): the transposed tap j at p is w_{7-j}[p + off_j] = |g_j[p]| / S[p + off_j],
+ * so it is rebuilt from the raw guidance (f32, channels 0..7 through the strides, as cspn3_forward_resident reads it) at the
+ * quad ITSELF and the forward's refined reciprocal of the published normaliser S [B,H,W] at the 3 x 3 neighbours.  For
+ * normalisers in [2^-100, 2^100] the taps — hence history — are bit-identical to cspn3_transposed_resident on the volume the
+ * forward would have published.  Everything else as cspn3_transposed_resident. */
+int cspn3_transposed_resident_guidance(const void* guidance, long g_batch_stride, long g_chan_stride, const float* s,
+                                       const float* g_T, const float* sparse_f32_or_null, float* history, void* work,
+                                       unsigned seq, unsigned* host_err_or_null, int B, int H, int W, int W_valid, int T,
+                                       int premask, const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
 
 /* The K x K softmax / pixel-adaptive variant (reference: network/libs/post_process/CSPN_ours.py:24-54 — softmax :35, zero
  * centre tap :37-39, prop_time x { pac.conv2d :49 -> base/pac.py:89-92, sparse blend :51-53 }) as weight-resident launches:

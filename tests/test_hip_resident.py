@@ -274,6 +274,57 @@ def test_resident_reverse_sweep_equals_multi_launch(B, H, W, T, sparse, c_oracle
     F.check_resident_errors()
 
 
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (2, 37, 8, 7), (5, 60, 64, 9), (2, 7, 12, 3)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_volume_free_reverse_sweep_equals_the_sweep_on_the_published_volume(B, H, W, T, sparse, c_oracle):
+    """cspn3_transposed_resident_guidance rebuilds the transposed taps |g_j[p]| / S[p + off_j] from the raw guidance and the
+    normaliser S (ABI 9) instead of gathering them from the 8-plane volume: every G_t plane bit for bit equal to the sweep on the
+    volume — also with a 12-channel guidance read through its strides, and with the S the TRAINING forward publishes when it is
+    told not to write the volume (publish_weights=False), whose history and S equal the publishing launch's."""
+    g, d, s = c_oracle.synthetic_inputs(190 + B + T, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    cot = dev(c_oracle.hash_normal(191, 9, (B, H, W)))
+    gd, d0 = dev(g), dev(d)[:, 0].contiguous()
+    sp = dev(s)[:, 0].contiguous() if sparse else None
+    with torch.no_grad():
+        w8, S, _ = F.cspn3_prepare(gd, want_s=True)
+    with resident("off"):
+        _, ref = F._reverse_sweep(w8, 3, T, sp, cot, None)
+    with resident("on"):
+        direct = F.transposed_resident_guidance(gd, S, cot, sp, T)
+        _, via = F._reverse_sweep(None, 3, T, sp, cot, None, guidance_S=(gd, S))
+        assert torch.equal(direct, ref) and torch.equal(via, ref)
+        if F.resident_supported(gd, d0, sp, T) is not None:
+            blend = F.BLEND_SPARSE if sparse else F.BLEND_NONE
+            o1, h1, w1, S1 = F.forward_resident(gd, d0, sp, T, blend, keep_history=True)
+            o2, h2, w2, S2 = F.forward_resident(gd, d0, sp, T, blend, keep_history=True, publish_weights=False)
+            assert w2 is None and torch.equal(h1, h2) and torch.equal(S1, S2) and torch.equal(w1, w8) and torch.equal(S1, S)
+            assert torch.equal(F.transposed_resident_guidance(gd, S2, cot, sp, T), ref)
+    with resident("off"):          # no resident sweep: the volume is rebuilt by cspn3_prepare, the streaming launches run on it
+        _, off = F._reverse_sweep(None, 3, T, sp, cot, None, guidance_S=(gd, S))
+    assert torch.equal(off, ref)
+    F.check_resident_errors()
+
+
+def test_training_step_without_the_tap_volume_equals_the_one_with_it(c_oracle, monkeypatch):
+    """The default training path publishes S only (forward), rebuilds the taps in the reverse sweep and in the tail;
+    CSPN_TRAIN_VOLUME=1 keeps the 8-plane volume.  Same output, same gradients, bit for bit — plain and with a sparse depth."""
+    B, H, W, T = 24, 228, 304, 24
+    for sparse in (False, True):
+        g, d, s = c_oracle.synthetic_inputs(230, B, H, W, 12, 500 if sparse else None)
+        cot = dev(c_oracle.hash_normal(231, 9, (B, 1, H, W)))
+        res = []
+        for keep in ("0", "1"):
+            monkeypatch.setenv("CSPN_TRAIN_VOLUME", keep)
+            gt, dt = dev(g).requires_grad_(True), dev(d).requires_grad_(True)
+            out = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dt, dev(s) if sparse else None)
+            out.backward(cot)
+            res.append((out.detach(), gt.grad, dt.grad))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    F.check_resident_errors()
+
+
 class spin_limit(object):
     """Force the neighbour wait of every resident launch issued inside the block to give up after `n` polls."""
 
