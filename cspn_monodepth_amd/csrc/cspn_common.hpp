@@ -28,7 +28,7 @@ int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_byte
 // W % 8 == 0 (launched by the cspn_pac_conv2d* entry points of pac_conv2d.hip when every base pointer is 16-byte aligned)
 struct PacS2Args {
     int B, C, CK, H, W, Ho, Wo, WQ;      // WQ = Wo / 4 = W / 8 quads per output row
-    int cchunk;                          // channels per blockIdx.y (set by the launcher)
+    int cchunk, nchunk, gx;              // channels per chunk, chunks, spatial workgroups per image (set by the launcher)
 };
 bool pac_s2_geometry(int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int W);
 int pac_s2_forward(const void* in, const void* kern, void* out, int dtype, int K, const PacS2Args& a, void* stream);

@@ -8,8 +8,9 @@
 // outputs, all of them inside an 8-pixel octet + a 1-2 pixel fringe.  So there is nothing to stage:
 //   * a thread owns one quad of 4 consecutive OUTPUT pixels (oy, 4qx..4qx+3) = one aligned octet 8qx..8qx+7 of each of the K
 //     input rows 2oy-P .. 2oy-P+K-1 (two 16-byte loads in fp32, one in fp16), flat index over (oy, qx): no tile quantisation;
-//   * the fringe (P columns to the left, P-1 to the right) comes from the neighbouring lanes by DPP wave shifts; only the
-//     first / last lane of a wavefront inside a row patches with scalar loads, row ends are the zero padding;
+//   * the fringe (P columns to the left, P-1 to the right) is fetched by the lane itself with scalar loads of lines the
+//     neighbouring lanes' octets bring in anyway (row ends are the zero padding); every load of a batch is issued before the
+//     first is consumed (see RowRaw);
 //   * the window walk is pure register arithmetic with compile-time indices: out[e] += k[i][j][e] * ext_i[2e + j];
 //   * dL/dkernel is the same walk with the roles of kernel and grad_out swapped; a shared kernel (kernel_ch = 1) sums over
 //     channels in registers, the wavefronts of a workgroup split the channels and meet in LDS in a fixed order (deterministic);
@@ -72,31 +73,82 @@ __device__ __forceinline__ void ldq(const T* p, float (&v)[4]) {
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
 
-// One input row of the window walk: ext[m] = row[8qx - P + m] (0 where the window sees padding).  `row` is always a valid
-// address (the caller clamps the row index); rok says whether the row exists.
+// One input row of the window walk in two phases, so that EVERY load of a batch (all rows, all channels in flight) is issued
+// before the first one is consumed: RowRaw holds the raw bits of the aligned octet and of the fringe columns (P to the left,
+// P - 1 to the right), each fringe column fetched by the lane itself with a 4- / 2-byte load from a clamped (always valid)
+// address — the lines are the ones the neighbouring lanes' octets bring in anyway.  (The first version took the fringe from the
+// neighbouring lanes by DPP and patched the first / last lane of a wavefront under a branch: the DPP moves sat right behind each
+// row's loads and the patch blocks fenced the scheduler in, so a K-row window cost K serialised round trips per channel —
+// `s_waitcnt vmcnt(1)` after every pair of octet loads; the K = 5 forward ran at a quarter of the HBM peak.)
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<__half> { uint4 r; };
+__device__ __forceinline__ void ld8_raw(const float* p, Raw8<float>& o) { o.a = ld4(p); o.b = ld4(p + 4); }
+__device__ __forceinline__ void ld8_raw(const __half* p, Raw8<__half>& o) { o.r = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ unsigned ld1_raw(const float* p) { return __float_as_uint(*p); }
+__device__ __forceinline__ unsigned ld1_raw(const __half* p) { return *reinterpret_cast<const unsigned short*>(p); }
+__device__ __forceinline__ void cvt8(const Raw8<float>& r, float (&o)[8]) {
+    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+}
+__device__ __forceinline__ void cvt8(const Raw8<__half>& r, float (&o)[8]) {
+    const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.r.x));
+    const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r.r.y));
+    const float2 c = __half22float2(*reinterpret_cast<const __half2*>(&r.r.z));
+    const float2 d = __half22float2(*reinterpret_cast<const __half2*>(&r.r.w));
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
+}
+template <typename T> __device__ __forceinline__ float cvt1(unsigned raw);
+template <> __device__ __forceinline__ float cvt1<float>(unsigned raw) { return __uint_as_float(raw); }
+template <> __device__ __forceinline__ float cvt1<__half>(unsigned raw) { return __half2float(__ushort_as_half((unsigned short)raw)); }
+
+template <typename T, int K> struct RowRaw {
+    Raw8<T> oct;
+    unsigned fringe[S2<K>::LH + S2<K>::RH];
+};
+// `row` is always a valid address (the caller clamps the row index)
 template <typename T, int K>
-__device__ __forceinline__ void load_ext_row(const T* row, bool rok, int qx, int WQ, bool fixl, bool fixr,
-                                             float (&ext)[S2<K>::EXT]) {
+__device__ __forceinline__ void issue_row(const T* row, int qx, int WQ, RowRaw<T, K>& r) {
+    typedef S2<K> G;
+    ld8_raw(row + 8 * qx, r.oct);
+#pragma unroll
+    for (int m = 0; m < G::LH; ++m) r.fringe[m] = ld1_raw(row + (qx > 0 ? 8 * qx - G::LH + m : 0));
+#pragma unroll
+    for (int m = 0; m < G::RH; ++m) r.fringe[G::LH + m] = ld1_raw(row + (qx < WQ - 1 ? 8 * qx + 8 + m : 0));
+}
+// ext[m] = row[8qx - P + m], 0 where the window sees padding (rok: the row exists)
+template <typename T, int K>
+__device__ __forceinline__ void finish_row(const RowRaw<T, K>& r, bool rok, int qx, int WQ, float (&ext)[S2<K>::EXT]) {
     typedef S2<K> G;
     float o[8];
-    ld8(row + 8 * qx, o);
+    cvt8(r.oct, o);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        o[m] = rok ? o[m] : 0.f;
-        ext[G::LH + m] = o[m];
-    }
+    for (int m = 0; m < 8; ++m) ext[G::LH + m] = rok ? o[m] : 0.f;
 #pragma unroll
-    for (int m = 0; m < G::LH; ++m) {
-        float v = dpp_from_prev_lane(o[8 - G::LH + m]);
-        if (fixl) v = (qx > 0 && rok) ? ld1(row + 8 * qx - G::LH + m) : 0.f;
-        ext[m] = v;
-    }
+    for (int m = 0; m < G::LH; ++m) ext[m] = (rok && qx > 0) ? cvt1<T>(r.fringe[m]) : 0.f;
 #pragma unroll
-    for (int m = 0; m < G::RH; ++m) {
-        float v = dpp_from_next_lane(o[m]);
-        if (fixr) v = (qx < WQ - 1 && rok) ? ld1(row + 8 * qx + 8 + m) : 0.f;
-        ext[G::LH + 8 + m] = v;
-    }
+    for (int m = 0; m < G::RH; ++m) ext[G::LH + 8 + m] = (rok && qx < WQ - 1) ? cvt1<T>(r.fringe[G::LH + m]) : 0.f;
+}
+
+// Workgroup -> (image, spatial block, channel chunk) of the chunked launches.  Every chunk of a spatial block reads the same
+// K*K kernel quads per thread; with a (spatial, chunk, image) grid the chunks of one block are 17 workgroups apart and land on
+// eight DIFFERENT XCDs (the dispatcher deals workgroups out round-robin), i.e. on eight private L2s: the kernel planes were
+// fetched from memory once per chunk — at K = 5 more bytes than the input itself.  Here the linear id is decoded so that the
+// chunks of a spatial block are the workgroups L, L + 8, L + 16, ...: same XCD, consecutive in time, the taps of all but the
+// first come out of that XCD's L2.
+struct Chunked {
+    int b, bx, c0;
+    bool any;
+};
+__device__ __forceinline__ Chunked chunked_id(const PacS2Args& a) {
+    const int L = blockIdx.x, r = L & 7, q = L >> 3;
+    const int y = q % a.nchunk, sg = q / a.nchunk;
+    const int sidx = sg * 8 + r;
+    Chunked c;
+    c.any = sidx < a.gx * a.B;
+    c.b = c.any ? sidx / a.gx : 0;
+    c.bx = sidx - c.b * a.gx;
+    c.c0 = y * a.cchunk;
+    return c;
 }
 
 struct Where {
@@ -120,9 +172,11 @@ template <typename T, int K, bool SHARED, int CB>
 __global__ __launch_bounds__(256) void pac_s2_fwd(const T* __restrict__ in, const T* __restrict__ kern, T* __restrict__ out,
                                                   const PacS2Args a) {
     typedef S2<K> G;
-    const Where w = where_am_i(blockIdx.x * 256 + threadIdx.x, a.Ho, a.WQ);
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
+    const Chunked ck = chunked_id(a);
+    if (!ck.any) return;
+    const Where w = where_am_i(ck.bx * 256 + threadIdx.x, a.Ho, a.WQ);
+    const int b = ck.b;
+    const int c0 = ck.c0, c1 = min(a.C, c0 + a.cchunk);
     const size_t iplane = (size_t)a.H * a.W, oplane = (size_t)a.Ho * a.Wo;
     const size_t opix = (size_t)w.oy * a.Wo + 4 * w.qx;
     int rowoff[K];
@@ -139,13 +193,13 @@ __global__ __launch_bounds__(256) void pac_s2_fwd(const T* __restrict__ in, cons
         for (int t = 0; t < G::NT; ++t) ldq(kern + ((size_t)b * G::NT + t) * oplane + opix, kv[t]);
     }
     for (int c = c0; c < c1; c += CB) {
-        float ext[CB][K][G::EXT];
+        RowRaw<T, K> raw[CB][K];
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
             const int cu = min(c + cc, c1 - 1);
             const T* pl = in + ((size_t)b * a.C + cu) * iplane;
 #pragma unroll
-            for (int i = 0; i < K; ++i) load_ext_row<T, K>(pl + rowoff[i], rok[i], w.qx, a.WQ, w.fixl, w.fixr, ext[cc][i]);
+            for (int i = 0; i < K; ++i) issue_row<T, K>(pl + rowoff[i], w.qx, a.WQ, raw[cc][i]);
         }
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
@@ -156,11 +210,14 @@ __global__ __launch_bounds__(256) void pac_s2_fwd(const T* __restrict__ in, cons
             }
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < K; ++i)
+            for (int i = 0; i < K; ++i) {
+                float ext[G::EXT];
+                finish_row<T, K>(raw[cc][i], rok[i], w.qx, a.WQ, ext);
 #pragma unroll
                 for (int j = 0; j < K; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(kv[i * K + j][e], ext[cc][i][2 * e + j], acc[e]);
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(kv[i * K + j][e], ext[2 * e + j], acc[e]);
+            }
             if (w.live && c + cc < c1)
                 st4(out + ((size_t)b * a.C + cu) * oplane + opix, make_float4(acc[0], acc[1], acc[2], acc[3]));
         }
@@ -173,9 +230,11 @@ template <typename T, int K, int CB>
 __global__ __launch_bounds__(256) void pac_s2_gk_perch(const T* __restrict__ gout, const T* __restrict__ in, T* __restrict__ gk,
                                                        const PacS2Args a) {
     typedef S2<K> G;
-    const Where w = where_am_i(blockIdx.x * 256 + threadIdx.x, a.Ho, a.WQ);
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
+    const Chunked ck = chunked_id(a);
+    if (!ck.any) return;
+    const Where w = where_am_i(ck.bx * 256 + threadIdx.x, a.Ho, a.WQ);
+    const int b = ck.b;
+    const int c0 = ck.c0, c1 = min(a.C, c0 + a.cchunk);
     const size_t iplane = (size_t)a.H * a.W, oplane = (size_t)a.Ho * a.Wo;
     const size_t opix = (size_t)w.oy * a.Wo + 4 * w.qx;
     int rowoff[K];
@@ -187,7 +246,7 @@ __global__ __launch_bounds__(256) void pac_s2_gk_perch(const T* __restrict__ gou
         rowoff[i] = (rok[i] ? yi : 0) * a.W;
     }
     for (int c = c0; c < c1; c += CB) {
-        float ext[CB][K][G::EXT];
+        RowRaw<T, K> raw[CB][K];
         float g[CB][4];
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
@@ -195,19 +254,21 @@ __global__ __launch_bounds__(256) void pac_s2_gk_perch(const T* __restrict__ gou
             const T* pl = in + ((size_t)b * a.C + cu) * iplane;
             ldq(gout + ((size_t)b * a.C + cu) * oplane + opix, g[cc]);
 #pragma unroll
-            for (int i = 0; i < K; ++i) load_ext_row<T, K>(pl + rowoff[i], rok[i], w.qx, a.WQ, w.fixl, w.fixr, ext[cc][i]);
+            for (int i = 0; i < K; ++i) issue_row<T, K>(pl + rowoff[i], w.qx, a.WQ, raw[cc][i]);
         }
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
             if (w.live && c + cc < c1) {
                 T* dst = gk + ((size_t)b * a.C + c + cc) * G::NT * oplane + opix;
 #pragma unroll
-                for (int i = 0; i < K; ++i)
+                for (int i = 0; i < K; ++i) {
+                    float ext[G::EXT];
+                    finish_row<T, K>(raw[cc][i], rok[i], w.qx, a.WQ, ext);
 #pragma unroll
                     for (int j = 0; j < K; ++j)
                         st4(dst + (size_t)(i * K + j) * oplane,
-                            make_float4(g[cc][0] * ext[cc][i][j], g[cc][1] * ext[cc][i][2 + j], g[cc][2] * ext[cc][i][4 + j],
-                                        g[cc][3] * ext[cc][i][6 + j]));
+                            make_float4(g[cc][0] * ext[j], g[cc][1] * ext[2 + j], g[cc][2] * ext[4 + j], g[cc][3] * ext[6 + j]));
+                }
             }
         }
     }
@@ -239,28 +300,31 @@ __global__ __launch_bounds__(64 * NW) void pac_s2_gk_shared(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
     for (int c = wave * CB; c < a.C; c += NW * CB) {
-        float ext[CB][K][G::EXT];
+        RowRaw<T, K> raw[CB][K];
         float g[CB][4];
 #pragma unroll
         for (int cc = 0; cc < CB; ++cc) {
-            const bool cok = c + cc < a.C;
-            const int cu = cok ? c + cc : a.C - 1;
+            const int cu = min(c + cc, a.C - 1);
             const T* pl = in + ((size_t)b * a.C + cu) * iplane;
             ldq(gout + ((size_t)b * a.C + cu) * oplane + opix, g[cc]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[cc][e] = cok ? g[cc][e] : 0.f;
-#pragma unroll
-            for (int i = 0; i < K; ++i)
-                load_ext_row<T, K>(pl + rowoff[i], rok[i] && cok, w.qx, a.WQ, w.fixl, w.fixr, ext[cc][i]);
+            for (int i = 0; i < K; ++i) issue_row<T, K>(pl + rowoff[i], w.qx, a.WQ, raw[cc][i]);
         }
 #pragma unroll
-        for (int cc = 0; cc < CB; ++cc)
+        for (int cc = 0; cc < CB; ++cc) {
+            const bool cok = c + cc < a.C;
 #pragma unroll
-            for (int i = 0; i < K; ++i)
+            for (int e = 0; e < 4; ++e) g[cc][e] = cok ? g[cc][e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float ext[G::EXT];
+                finish_row<T, K>(raw[cc][i], rok[i] && cok, w.qx, a.WQ, ext);
 #pragma unroll
                 for (int j = 0; j < K; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i * K + j][e] = fmaf(g[cc][e], ext[cc][i][2 * e + j], acc[i * K + j][e]);
+                    for (int e = 0; e < 4; ++e) acc[i * K + j][e] = fmaf(g[cc][e], ext[2 * e + j], acc[i * K + j][e]);
+            }
+        }
     }
     if constexpr (NW > 1) {
         if (wave > 0) {
@@ -289,10 +353,12 @@ template <typename T, int K, bool SHARED, int CB>
 __global__ __launch_bounds__(256) void pac_s2_gi(const T* __restrict__ gout, const T* __restrict__ kern, T* __restrict__ gin,
                                                  const PacS2Args a) {
     typedef S2<K> G;
-    const Where w = where_am_i(blockIdx.x * 256 + threadIdx.x, a.Ho, a.WQ);     // (yp, qx): input rows 2yp, 2yp+1, octet 8qx
+    const Chunked ck = chunked_id(a);
+    if (!ck.any) return;
+    const Where w = where_am_i(ck.bx * 256 + threadIdx.x, a.Ho, a.WQ);     // (yp, qx): input rows 2yp, 2yp+1, octet 8qx
     const int yp = w.oy;
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
+    const int b = ck.b;
+    const int c0 = ck.c0, c1 = min(a.C, c0 + a.cchunk);
     const size_t iplane = (size_t)a.H * a.W, oplane = (size_t)a.Ho * a.Wo;
     const bool patch_l = w.fixl && w.qx > 0, patch_r = w.fixr && w.qx < a.WQ - 1;     // a neighbour exists, in another wavefront
     size_t rpix[G::NR];                 // grad_out / kernel quad of row yp + DMIN + r (clamped to a valid row)
@@ -380,6 +446,16 @@ __global__ __launch_bounds__(256) void pac_s2_gi(const T* __restrict__ gout, con
 }
 
 // ------------------------------------------------------------------------------------------------ host
+#ifndef CSPN_S2_WANT
+#define CSPN_S2_WANT 1024      // workgroups a chunked launch aims for (channel chunks are split until there are that many)
+#endif
+// 1-D grid of the chunked launches: the spatial blocks of all images padded to a multiple of 8, times the chunks (see chunked_id)
+inline dim3 chunked_grid(PacS2Args& a, int gx) {
+    a.gx = gx;
+    a.nchunk = ceil_div(a.C, a.cchunk);
+    return dim3((unsigned)(ceil_div(gx * a.B, 8) * 8 * a.nchunk));
+}
+
 inline int chunk_for(int C, size_t spatial_blocks, int CB, size_t want) {
     if (spatial_blocks >= want) return C;
     size_t nchunk = (want + spatial_blocks - 1) / spatial_blocks;
@@ -396,8 +472,8 @@ int forward_k(const void* in_, const void* kern_, void* out_, PacS2Args a, hipSt
     T* out = static_cast<T*>(out_);
     constexpr int CB = K == 3 ? 2 : 1;
     const int gx = ceil_div(a.Ho * a.WQ, 256);
-    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 1024);
-    const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
+    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, CSPN_S2_WANT);
+    const dim3 grid = chunked_grid(a, gx), block(256);
     if (a.CK == 1) pac_s2_fwd<T, K, true, CB><<<grid, block, 0, st>>>(in, kern, out, a);
     else pac_s2_fwd<T, K, false, CB><<<grid, block, 0, st>>>(in, kern, out, a);
     HIP_OK(hipGetLastError());
@@ -411,8 +487,8 @@ int grad_input_k(const void* gout_, const void* kern_, void* gin_, PacS2Args a, 
     T* gin = static_cast<T*>(gin_);
     constexpr int CB = K == 3 ? 2 : 1;
     const int gx = ceil_div(a.Ho * a.WQ, 256);
-    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 1024);
-    const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
+    a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, CSPN_S2_WANT);
+    const dim3 grid = chunked_grid(a, gx), block(256);
     if (a.CK == 1) pac_s2_gi<T, K, true, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
     else pac_s2_gi<T, K, false, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
     HIP_OK(hipGetLastError());
@@ -432,8 +508,8 @@ int grad_kernel_k(const void* gout_, const void* in_, void* gk_, PacS2Args a, hi
     } else {
         constexpr int CB = K == 3 ? 2 : 1;
         const int gx = ceil_div(a.Ho * a.WQ, 256);
-        a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, 1024);
-        const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
+        a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, CSPN_S2_WANT);
+        const dim3 grid = chunked_grid(a, gx), block(256);
         pac_s2_gk_perch<T, K, CB><<<grid, block, 0, st>>>(gout, in, gk, a);
     }
     HIP_OK(hipGetLastError());

@@ -14,11 +14,11 @@ lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(lo, hi):
     for fn in (t.test_fuzz_geometry_vs_oracle, t.test_fuzz_tiled_geometry_both_kernels,
-               t.test_fuzz_unit_stride_dilated_and_rectangular_windows):
+               t.test_fuzz_unit_stride_dilated_and_rectangular_windows, t.test_fuzz_stride2_register_kernels_and_generic):
         try:
             fn(seed)
         except AssertionError:
             bad += 1
             print("seed %d %s:" % (seed, fn.__name__))
             traceback.print_exc(limit=1)
-print("seeds %d..%d x 3 sweeps: %d failing cases" % (lo, hi, bad))
+print("seeds %d..%d x 4 sweeps: %d failing cases" % (lo, hi, bad))

@@ -38,6 +38,10 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
             F.set_resident("off"); _, gh0 = F._reverse_sweep(w0, 3, T, s, gT, None)
             F.set_resident("on"); _, gh1 = F._reverse_sweep(w0, 3, T, s, gT, None)
             ok = ok and torch.equal(gh0, gh1)
+            # the volume-free forms (ABI 9): S-only training forward, reverse sweep rebuilt from guidance + S
+            _, h2, w2, S2 = F.forward_resident(g, d, s, T, int(sparse), keep_history=True, publish_weights=False)
+            gh2 = F.transposed_resident_guidance(g, S2, gT, s, T)
+            ok = ok and w2 is None and torch.equal(h0, h2) and torch.equal(S0, S2) and torch.equal(gh0, gh2)
             a0, a1 = ev.new_accumulator(dev), ev.new_accumulator(dev)
             m = pkg.CSPN_new.AffinityPropagate(T, 3)
             o1 = m.forward_scored(g, d.unsqueeze(1), None if s is None else s.unsqueeze(1), tg.unsqueeze(1), a1)
