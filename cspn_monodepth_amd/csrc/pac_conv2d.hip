@@ -26,7 +26,10 @@ std::atomic<int>& force_generic_flag() {
 
 // workgroups the any-geometry launches aim for (channel chunks / tap groups are split until there are that many): measured on
 // the C = 32 dilated row — 512 / 1024 / 2048 workgroups: forward 57 / 47 / 54 us; dL/dkernel with 1 / 2 tap groups: 58 / 88 us
-constexpr size_t ANY_WANT_WGS = 1024, ANY_WANT_WGS_GK = 256;
+#ifndef CSPN_PAC_WANT_WGS
+#define CSPN_PAC_WANT_WGS 1024
+#endif
+constexpr size_t ANY_WANT_WGS = CSPN_PAC_WANT_WGS, ANY_WANT_WGS_GK = 256;
 
 struct ConvArgs {
     int B, C, CK, H, W, Ho, Wo, WQ;      // WQ = ceil(Wo / 4) output quads per row
@@ -36,7 +39,34 @@ struct ConvArgs {
     int cchunk;                          // channels per blockIdx.y
     int vec;                             // Wo % 4 == 0 and 16-byte (8 for f16) aligned bases: quad loads/stores
     int force_scalar;                    // CSPN_PAC_SCALAR=1 in the environment: skip the tiled kernels (A/B, tests)
+    int lin_tiles, lin_chunks;           // > 0: 1-D grid, decoded by wg_id (the channel chunks of a tile share an XCD)
 };
+
+// Workgroup -> (tile, channel chunk, image).  The chunked launches of a SHARED kernel read the tile's kh*kw kernel quads once per
+// chunk; on a (tile, chunk, image) grid the chunks of one tile are `tiles` workgroups apart and land on different XCDs (the
+// dispatcher deals workgroups out round-robin over the eight XCDs), i.e. on different private L2s — the kernel planes, the bulk of
+// the traffic at K = 5 / 7, came from memory once per chunk.  With lin_chunks > 0 the grid is 1-D and decoded so that the chunks
+// of a tile are the workgroups L, L + 8, L + 16, ...: same XCD, consecutive in time, every chunk but the first finds the taps in
+// that XCD's L2.  (Speed only: any mapping is correct.)
+struct WgId {
+    int x, y, z;
+    bool any;
+};
+__device__ __forceinline__ WgId wg_id(int lin_tiles, int lin_chunks, int B) {
+    WgId w;
+    if (lin_chunks <= 0) {
+        w.x = blockIdx.x; w.y = blockIdx.y; w.z = blockIdx.z; w.any = true;
+        return w;
+    }
+    const int L = blockIdx.x, r = L & 7, q = L >> 3;
+    w.y = q % lin_chunks;
+    const int sidx = (q / lin_chunks) * 8 + r;
+    w.any = sidx < lin_tiles * B;
+    w.z = w.any ? sidx / lin_tiles : 0;
+    w.x = sidx - w.z * lin_tiles;
+    return w;
+}
+inline dim3 lin_grid(int tiles, int chunks, int B) { return dim3((unsigned)(((tiles * B + 7) / 8) * 8 * chunks)); }
 
 // source index along one axis for output index o and tap t, or -1 where the window sees a zero
 __device__ __forceinline__ int src_plain(int o, int t, int S, int P, int D, int N) {
@@ -182,6 +212,7 @@ struct TiledArgs {
     int k_h, k_w;            // kernel planes: always [Ho, Wo]
     int k_vec, dst_vec;      // aligned quads possible on the kernel planes (forward only) / the destination
     int tiles_x;
+    int lin_tiles, lin_chunks;   // > 0: 1-D grid, decoded by wg_id
 };
 
 // NBUF = 1: the whole channel chunk is ONE batch (cchunk <= CB, the host's promise) — no second LDS buffer, twice the workgroups per CU
@@ -197,14 +228,16 @@ __global__ __launch_bounds__(256, (K > 5 && (CB <= 4 || NBUF == 1) ? 2 : 1)) voi
     constexpr int KR = ROWWISE ? K : K * K;
     constexpr int ROW_UNROLL = ROWWISE ? 1 : K;         // row-wise: a real loop, or the tap loads are hoisted and spill
     __shared__ __attribute__((aligned(16))) float tile[NBUF][CB][PATCH];
-    const int tid = blockIdx.x;
+    const WgId wg = wg_id(a.lin_tiles, a.lin_chunks, a.B);
+    if (!wg.any) return;
+    const int tid = wg.x;
     const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
     const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
     const int qx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int x0 = tx0 + 4 * qx, y = ty0 + ly;
     const bool live = y < a.dst_h && x0 < a.dst_w;
-    const int b = blockIdx.z;
-    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const int b = wg.z;
+    const int c_begin = wg.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
     const size_t kplane = (size_t)a.k_h * a.k_w, splane = (size_t)a.src_h * a.src_w, dplane = (size_t)a.dst_h * a.dst_w;
     const size_t dpix = (size_t)y * a.dst_w + x0;
 
@@ -378,14 +411,16 @@ __global__ __launch_bounds__(256, (HOIST ? 1 : 4)) void pac_conv2d_tiled_h8(cons
     constexpr int NLD = (PATCH + 255) / 256;
     constexpr int NQUAD = (K + 7 + 3) / 4;              // aligned quads covering the K+7 window columns
     __shared__ __attribute__((aligned(16))) float tile[2][PATCH];
-    const int tid = blockIdx.x;
+    const WgId wg = wg_id(a.lin_tiles, a.lin_chunks, a.B);
+    if (!wg.any) return;
+    const int tid = wg.x;
     const int ty = tid / a.tiles_x, tx = tid - ty * a.tiles_x;
     const int tx0 = tx * TILE_W8, ty0 = ty * TILE_H;
     const int ox = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int x0 = tx0 + 8 * ox, y = ty0 + ly;
     const bool live = y < a.dst_h && x0 < a.dst_w;      // dst_w % 8 == 0 (launcher): an oct is inside or outside as a whole
-    const int b = blockIdx.z;
-    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const int b = wg.z;
+    const int c_begin = wg.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
     const size_t kplane = (size_t)a.k_h * a.k_w, splane = (size_t)a.src_h * a.src_w, dplane = (size_t)a.dst_h * a.dst_w;
     const size_t dpix = (size_t)y * a.dst_w + x0;
 
@@ -528,13 +563,15 @@ __global__ __launch_bounds__(256) void pac_conv2d_fwd_tiled_any(const T* __restr
                                                                 T* __restrict__ out, ConvArgs a, int tiles_x, int RW,
                                                                 int RH, int cb) {
     extern __shared__ __attribute__((aligned(16))) float patch[];       // [cb][RH * RW]
-    const int tid = blockIdx.x;
+    const WgId wg = wg_id(a.lin_tiles, a.lin_chunks, a.B);
+    if (!wg.any) return;
+    const int tid = wg.x;
     const int ty = tid / tiles_x, tx = tid - ty * tiles_x;
     const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
     const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
     const int x = tx0 + lx;
-    const int b = blockIdx.z;
-    const int c_begin = blockIdx.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
+    const int b = wg.z;
+    const int c_begin = wg.y * a.cchunk, c_end = min(a.C, c_begin + a.cchunk);
     const int src_h = TRANSPOSED ? a.Ho : a.H, src_w = TRANSPOSED ? a.Wo : a.W;     // the plane the patch is cut from
     const int dst_h = TRANSPOSED ? a.H : a.Ho, dst_w = TRANSPOSED ? a.W : a.Wo;     // the plane the tile lies on
     const size_t kplane = (size_t)a.Ho * a.Wo, splane = (size_t)src_h * src_w, dplane = (size_t)dst_h * dst_w;
@@ -1266,7 +1303,8 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
             int nchunk8 = (int)std::min<size_t>((want8 + have8 - 1) / have8, (size_t)a.C);
             if (a.CK != 1) nchunk8 = (int)std::min<size_t>((4 * want8 + have8 - 1) / have8, (size_t)a.C);
             t.cchunk = ceil_div(a.C, std::max(nchunk8, 1));
-            const dim3 grid8(tiles8, ceil_div(a.C, t.cchunk), a.B), block8(256);
+            t.lin_tiles = tiles8; t.lin_chunks = ceil_div(a.C, t.cchunk);
+            const dim3 grid8 = lin_grid(tiles8, t.lin_chunks, a.B), block8(256);
             if (a.CK == 1 && t.cchunk > 1) pac_conv2d_tiled_h8<K, true><<<grid8, block8, 0, st>>>(src, kern, dst, t);
             else pac_conv2d_tiled_h8<K, false><<<grid8, block8, 0, st>>>(src, kern, dst, t);
             HIP_OK(hipGetLastError());
@@ -1280,7 +1318,8 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
     int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)a.C);
     if (a.CK != 1) nchunk = (int)std::min<size_t>((4 * want + have - 1) / have, (size_t)a.C);   // nothing is re-read
     t.cchunk = ceil_div(a.C, std::max(nchunk, 1));
-    const dim3 grid(tiles, ceil_div(a.C, t.cchunk), a.B), block(256);
+    t.lin_tiles = tiles; t.lin_chunks = ceil_div(a.C, t.cchunk);
+    const dim3 grid = lin_grid(tiles, t.lin_chunks, a.B), block(256);
     constexpr bool CAN_HOIST = K <= 5;                   // the whole window in registers
     const bool hoist = CAN_HOIST && a.CK == 1;
     if constexpr (K > 5) {
@@ -1289,7 +1328,8 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
         if (a.CK == 1 && a.C >= 8) {
             int nchunk8 = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, 8));
             t.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk8, 1)), 8) * 8;
-            const dim3 grid8(tiles, ceil_div(a.C, t.cchunk), a.B);
+            t.lin_chunks = ceil_div(a.C, t.cchunk);
+            const dim3 grid8 = lin_grid(tiles, t.lin_chunks, a.B);
             if (t.cchunk <= 8) pac_conv2d_tiled<T, K, false, 8, TRANSPOSED, 1><<<grid8, block, 0, st>>>(src, kern, dst, t);
             else pac_conv2d_tiled<T, K, false, 8, TRANSPOSED><<<grid8, block, 0, st>>>(src, kern, dst, t);
             HIP_OK(hipGetLastError());
@@ -1343,7 +1383,8 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
             const size_t want = ANY_WANT_WGS, have = (size_t)tiles * a.B;
             int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, cb));
             a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
-            const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
+            a.lin_tiles = tiles; a.lin_chunks = ceil_div(a.C, a.cchunk);
+            const dim3 grid = lin_grid(tiles, a.lin_chunks, a.B), block(256);
             const size_t lds = (size_t)cb * psz * sizeof(float);
             if (shared && a.kh * a.kw <= 9) pac_conv2d_fwd_tiled_any<T, true, false, true><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
             else if (shared) pac_conv2d_fwd_tiled_any<T, true, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
@@ -1516,7 +1557,8 @@ int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int
             const size_t want = ANY_WANT_WGS, have = (size_t)tiles * a.B;
             int nchunk = (int)std::min<size_t>((want + have - 1) / have, (size_t)ceil_div(a.C, cb));
             a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
-            const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
+            a.lin_tiles = tiles; a.lin_chunks = ceil_div(a.C, a.cchunk);
+            const dim3 grid = lin_grid(tiles, a.lin_chunks, a.B), block(256);
             const size_t lds = (size_t)cb * psz * sizeof(float);
             const T* g = static_cast<const T*>(gout);
             const T* k = static_cast<const T*>(kern);
