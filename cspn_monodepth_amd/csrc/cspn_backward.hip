@@ -141,12 +141,38 @@ struct TailArgs {
 // trip of the stream loop, serialised (cspn_grad_tail<5, __half, ...> ran at 302 us against 127 us for its fp32-history twin,
 // profiles/r04_kernel_stats_train_leg_pac5_state16.csv).  Raw loads from a safe address + a select after the conversion keep
 // every load of a trip in flight together; the empty asm pins the conversion behind the load phase.
+// Cache policy of the tails' single-use streams.  Every G quad is read by exactly one thread, every d row by the threads of three
+// rows: G loads that allocate in the L2 push out the d lines the neighbouring rows are about to re-read.  Non-temporal G loads
+// (bit 2), epilogue stores (4) and epilogue guidance loads (8): cspn_grad_tail<3, float, float, 1> 107.5-108.7 -> 89.5-93.0 us in a
+// same-box A/B (two alternating repetitions; G loads alone: 92.0-96.8); non-temporal loads of the d history (1) cost 4 us —
+// they are the re-used stream.  The K = 5 split tail does not care (66-69 us either way).  Results are bit-identical.
+#ifndef CSPN_TAIL_NT
+#define CSPN_TAIL_NT 14
+#endif
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 q) {
+    const v4f v = {q.x, q.y, q.z, q.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+}
+template <typename WT>
+__device__ __forceinline__ float4 ld4_ep(const WT* p) {
+    if constexpr (std::is_same<WT, float>::value && (CSPN_TAIL_NT & 8) != 0) return ld4_nt(p);
+    else return ld4(p);
+}
+template <typename WT>
+__device__ __forceinline__ void st4_ep(WT* p, float4 v) {
+    if constexpr (std::is_same<WT, float>::value && (CSPN_TAIL_NT & 4) != 0) st4_nt(p, v);
+    else st4(p, v);
+}
 template <typename DT> struct TailRaw;
 template <> struct TailRaw<float> {
     static constexpr bool RAW = false;        // fp32: the guarded loads themselves (no conversion to sink; 124 VGPRs = 4 waves per SIMD)
     typedef float4 Q;
     typedef float S;
-    static __device__ __forceinline__ Q ldq(const float* p) { return ld4(p); }
+    static __device__ __forceinline__ Q ldq(const float* p) { return (CSPN_TAIL_NT & 1) ? ld4_nt(p) : ld4(p); }
     static __device__ __forceinline__ S lds(const float* p) { return *p; }
     static __device__ __forceinline__ float4 f4(Q q) { return q; }
     static __device__ __forceinline__ float f1(S s) { return s; }
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
             const bool tv = live && t < T;
             const DT* d = (t == 0) ? d0 : dh + (size_t)(tv ? t - 1 : 0) * plane;
             const float* gsrc = (t == T - 1) ? a.g_T : a.ghist + (size_t)(tv ? T - 2 - t : 0) * plane;      // G_{t+1}
-            Gq[u] = tv ? ld4(gsrc + off) : z4;
+            Gq[u] = tv ? ((CSPN_TAIL_NT & 2) ? ld4_nt(gsrc + off) : ld4(gsrc + off)) : z4;
 #pragma unroll
             for (int rr = 0; rr < 2 * R + 1; ++rr) {
                 const int row = y + rr - R;
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
             const int ty = y + dy;
             const bool tok = ty >= 0 && ty < H;
             const size_t o = (size_t)(7 - j) * a.g_cs + (size_t)(tok ? ty : 0) * W + x;
-            const float4 q4 = ld4(g + o);
+            const float4 q4 = ld4_ep(g + o);
             gq[j][0] = tok ? q4.x : 0.f; gq[j][1] = tok ? q4.y : 0.f; gq[j][2] = tok ? q4.z : 0.f; gq[j][3] = tok ? q4.w : 0.f;
             gl[j] = gr[j] = 0.f;
             if (dx > 0 && lane == 63 && qx < WQ - 1 && tok) gr[j] = ld1(g + o + 4);
@@ -425,13 +451,13 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
                 const float4 gs = sgn4(ld4(g + o));
 #endif
                 if (dx == 0) {
-                    st4(gg + o, make_float4(gs.x * gA[0], gs.y * gA[1], gs.z * gA[2], gs.w * gA[3]));
+                    st4_ep(gg + o, make_float4(gs.x * gA[0], gs.y * gA[1], gs.z * gA[2], gs.w * gA[3]));
                 } else if (dx > 0) {
                     const float v0 = (qx == 0) ? 0.f : from_prev;              // column 0 has no source
                     if (lane == 0 && qx > 0) {                                   // left neighbour lives in another wave
                         st1(gg + o + 1, gs.y * gA[0]); st1(gg + o + 2, gs.z * gA[1]); st1(gg + o + 3, gs.w * gA[2]);
                     } else {
-                        st4(gg + o, make_float4(gs.x * v0, gs.y * gA[0], gs.z * gA[1], gs.w * gA[2]));
+                        st4_ep(gg + o, make_float4(gs.x * v0, gs.y * gA[0], gs.z * gA[1], gs.w * gA[2]));
                     }
 #if CSPN_TAIL_REBUILD_W
                     if (lane == 63 && qx < WQ - 1) st1(gg + o + 4, gs_r * gA[3]);
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
                     if (lane == 63 && qx < WQ - 1) {
                         st1(gg + o, gs.x * gA[1]); st1(gg + o + 1, gs.y * gA[2]); st1(gg + o + 2, gs.z * gA[3]);
                     } else {
-                        st4(gg + o, make_float4(gs.x * gA[1], gs.y * gA[2], gs.z * gA[3], gs.w * v3));
+                        st4_ep(gg + o, make_float4(gs.x * gA[1], gs.y * gA[2], gs.z * gA[3], gs.w * v3));
                     }
 #if CSPN_TAIL_REBUILD_W
                     if (lane == 0 && qx > 0) st1(gg + o - 1, gs_l * gA[0]);
@@ -454,9 +480,9 @@ __global__ __launch_bounds__(256) void cspn_grad_tail(const TailArgs a) {
             }
             // rows of this plane that no source row reaches: row 0 (dy=+1) / row H-1 (dy=-1)
             if ((dy > 0 && y == 0) || (dy < 0 && y == H - 1))
-                st4(gg + cplane + (size_t)y * W + x, make_float4(0.f, 0.f, 0.f, 0.f));
+                st4_ep(gg + cplane + (size_t)y * W + x, make_float4(0.f, 0.f, 0.f, 0.f));
         }
-        for (int c = 8; c < a.C; ++c) st4(gg + (size_t)c * a.g_cs + (size_t)y * W + x, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int c = 8; c < a.C; ++c) st4_ep(gg + (size_t)c * a.g_cs + (size_t)y * W + x, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
 
@@ -581,7 +607,7 @@ __device__ __forceinline__ void tail5_half(const TailArgs& a, float4 (*xdot)[128
             const int tc = t < T ? t : T - 1;           // a step past the end re-reads the last one; its G is zeroed below
             const DT* d = ((tc == 0) ? d0 : dh + (size_t)(tc - 1) * plane) + (size_t)b * HW;
             const float* gsrc = (tc == T - 1) ? a.g_T : a.ghist + (size_t)(T - 2 - tc) * plane;      // G_{t+1}
-            Gq[u] = ld4(gsrc + off);
+            Gq[u] = (CSPN_TAIL_NT & 2) ? ld4_nt(gsrc + off) : ld4(gsrc + off);
 #pragma unroll
             for (int rr = 0; rr < RR; ++rr) {
                 const DT* rp = d + rowoff[rr];

@@ -100,6 +100,19 @@ __device__ __forceinline__ void st4(gptr p, float4 v) {
     const v4f w = {v.x, v.y, v.z, v.w};
     *reinterpret_cast<GLB v4f*>(p) = w;
 }
+// The history planes of the training forms (d_1..d_T of MODE 2, G_{T-1}..G_0 of MODE 3 / 4: 160 MB per launch at config 2) are
+// written once and read by a LATER kernel: stored non-temporally they do not push the guidance / exchange lines out of the L2
+// while the launch runs, and the tail that streams them afterwards runs faster as well — same-box A/B, two alternating
+// repetitions: tail 95.2-97.1 -> 86.8-87.3 us, sparse training forward 69.7-70.3 -> 64.9-65.4, sparse reverse sweep 75.4-76.9 ->
+// 72.4-73.7, the plain forward / sweep -0 / -1.4 us (-DCSPN_RES_HIST_NT=0 for A/B).
+#ifndef CSPN_RES_HIST_NT
+#define CSPN_RES_HIST_NT 1
+#endif
+__device__ __forceinline__ void st4_hist(gptr p, float4 v) {
+    const v4f w = {v.x, v.y, v.z, v.w};
+    if (CSPN_RES_HIST_NT) __builtin_nontemporal_store(w, reinterpret_cast<GLB v4f*>(p));
+    else *reinterpret_cast<GLB v4f*>(p) = w;
+}
 __device__ __forceinline__ float4 ld4_dev(gptr p) {
     const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const GLB unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,7 +676,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) own[i][e] = keep[e];
                         if (HIST) {
-                            if ((interior >> i) & 1u) st4(at32(hist_step, (unsigned)((yq0L + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
+                            if ((interior >> i) & 1u) st4_hist(at32(hist_step, (unsigned)((yq0L + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
                         } else if (FINAL && ((interior >> i) & 1u)) {
                             st4(at32(dout, (unsigned)((yqx + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
                         }
