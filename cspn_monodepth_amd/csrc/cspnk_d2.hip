@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
                         const unsigned lo = wq[e][d2_slot(c)], hi = wq[e + 1][d2_slot(c)];
                         dw[k] = d2_half(c) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
                     }
-                    st16(atb(wkb, ((unsigned)i * 2u * hw4 + (qd + (unsigned)hq) * 8u) * 2u), make_uint4(dw[0], dw[1], dw[2], dw[3]));
+                    st16_hist(atb(wkb, ((unsigned)i * 2u * hw4 + (qd + (unsigned)hq) * 8u) * 2u), make_uint4(dw[0], dw[1], dw[2], dw[3]));
                 }
             }
         }
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
                 if (!CLEAN) { if (!in_img) o = make_uint4(0u, 0u, 0u, 0u); }        // zero padding stays exactly zero
                 if (kind == 1) { if (interior) st16_dev(xout, off_own * 2u, o); }
                 else if (kind == 2 && !HIST) { if (interior) st16(atb(outb, off_own * 2u), o); fin = o; }
-                if (HIST && interior) st16(atb(hist_step, off_own * 2u), o);
+                if (HIST && interior) st16_hist(atb(hist_step, off_own * 2u), o);
                 if (kind != 2 && active) *reinterpret_cast<uint4*>(wrb + (sy + R) * ls + 4 * (sx + 1)) = o;
             };
             const bool any = __ballot(active) != 0ull;       // wavefronts without a single owned row only keep the barriers company

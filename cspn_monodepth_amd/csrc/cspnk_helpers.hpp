@@ -56,6 +56,16 @@ __device__ __forceinline__ void st16(gptr p, uint4 v) {
     const v4u w = {v.x, v.y, v.z, v.w};
     *reinterpret_cast<GLB v4u*>(p) = w;
 }
+#ifndef CSPN_KRES_HIST_NT
+#define CSPN_KRES_HIST_NT 0     // A/B: 1 = non-temporal stores of the fp16 history planes / tap volume of the K x K training forms — measured
+                                // SLOWER (cspnk_d2 with history 83-85 -> 92-93 us, the transposed launches 44.4 -> 47.9 us), unlike the fp32 planes
+                                // of the 3 x 3 forms (cspn_resident.hip CSPN_RES_HIST_NT)
+#endif
+__device__ __forceinline__ void st16_hist(gptr p, uint4 v) {
+    const v4u w = {v.x, v.y, v.z, v.w};
+    if (CSPN_KRES_HIST_NT) __builtin_nontemporal_store(w, reinterpret_cast<GLB v4u*>(p));
+    else *reinterpret_cast<GLB v4u*>(p) = w;
+}
 __device__ __forceinline__ unsigned ld4u(gptr p) { return *reinterpret_cast<const GLB unsigned*>(p); }
 __device__ __forceinline__ uint2 ld8u(gptr p) {
     const v2u v = *reinterpret_cast<const GLB v2u*>(p);
@@ -104,6 +114,7 @@ template <> struct StateIO<__half> {
         return Oct{make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]))};
     }
     static __device__ __forceinline__ void st_oct(void* b, unsigned e, const Oct& o) { st16(atb(b, e * 2u), o.a); }
+    static __device__ __forceinline__ void st_oct_hist(void* b, unsigned e, const Oct& o) { st16_hist(atb(b, e * 2u), o.a); }
     static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 2u, o.a); }
 };
 template <> struct StateIO<float> {
@@ -123,6 +134,7 @@ template <> struct StateIO<float> {
                    make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]))};
     }
     static __device__ __forceinline__ void st_oct(void* b, unsigned e, const Oct& o) { st16(atb(b, e * 4u), o.a); st16(atb(b, e * 4u + 16u), o.b); }
+    static __device__ __forceinline__ void st_oct_hist(void* b, unsigned e, const Oct& o) { st16_hist(atb(b, e * 4u), o.a); st16_hist(atb(b, e * 4u + 16u), o.b); }
     static __device__ __forceinline__ void st_oct_dev(void* b, unsigned e, const Oct& o) { st16_dev(b, e * 4u, o.a); st16_dev(b, e * 4u + 16u, o.b); }
 };
 

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                 }
                 const bool inner = (interior >> i) & 1u;
                 const unsigned off = (unsigned)((yo0 + i) * W + xo);
-                if (TRANS && inner) IO::st_oct(hist_step, off, IO::from_f8(u));            // G_t itself goes to its history plane
+                if (TRANS && inner) IO::st_oct_hist(hist_step, off, IO::from_f8(u));            // G_t itself goes to its history plane
                 if (BLEND) {
                     const int q = (min(r0 + i, wr - 1) * wo + sx) * 8;
                     const float4 ma = *reinterpret_cast<const float4*>(md_lds + q), mb = *reinterpret_cast<const float4*>(md_lds + q + 4);
