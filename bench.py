@@ -139,12 +139,62 @@ def load_train_traffic(tag):
         return None
 
 
+_ORIG_AFFINITY = None        # the affinity mask this process was started with (bind_cpus narrows it for the GPU legs)
+
+
+def bind_cpus(local_rank, local_world, mode):
+    """Keep the host threads of a rank (Python, the autograd engine's worker, the HIP runtime's) on a few ADJACENT cores.
+    On the 256-thread hosts of the GPU boxes the scheduler otherwise spreads them over the sockets' CCDs, and a launch-rate-bound
+    leg then depends on where they happen to land: the training-shaped leg read 213-217 us per pass in some processes and 265-290 us
+    in others with IDENTICAL kernel times (rocprofv3: 86 + 61 + 60 us in every run) — bound to four cores it reads 213-217 us in
+    every run, and the headline value gains ~2 % (same-box A/B, five alternating runs; tools/probes/r04_train_bimodal.sh).
+    What `numactl` / `taskset` in a launch script would do; --cpu-bind off leaves the mask alone."""
+    global _ORIG_AFFINITY
+    if mode == "off":
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    _ORIG_AFFINITY = set(allowed)
+    k = 4 if len(allowed) >= 4 * max(local_world, 1) else len(allowed) // max(local_world, 1)
+    if k < 2:
+        return None
+    mine = allowed[(local_rank % max(local_world, 1)) * k:(local_rank % max(local_world, 1) + 1) * k]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
+class full_affinity(object):
+    """The CPU baseline runs on every core the process was given, not on the GPU legs' four."""
+
+    def __enter__(self):
+        self.cur = None
+        if _ORIG_AFFINITY is not None:
+            try:
+                self.cur = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, _ORIG_AFFINITY)
+            except OSError:
+                self.cur = None
+
+    def __exit__(self, *exc):
+        if self.cur is not None:
+            try:
+                os.sched_setaffinity(0, self.cur)
+            except OSError:
+                pass
+        return False
+
+
 def host_cpu_budget():
     """Cores this process may use: the scheduler affinity mask and the cgroup CPU quota (v2 cpu.max / v1 cfs quota), next
     to os.cpu_count() (which counts the machine's threads whatever the container is allowed)."""
     logical = os.cpu_count() or 1
     try:
-        affinity = len(os.sched_getaffinity(0))
+        affinity = len(_ORIG_AFFINITY) if _ORIG_AFFINITY is not None else len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         affinity = logical
     quota = None
@@ -443,7 +493,11 @@ def main():
                     help="--workload train: torch.backends.cudnn.benchmark (MIOpen find mode) as the reference's main.py:37; "
                          "slow first steps (minutes)")
     ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
+    ap.add_argument("--cpu-bind", choices=("auto", "off"), default="auto",
+                    help="auto: bind the rank's host threads to four adjacent cores of the allowed set (see bind_cpus); off: leave the mask alone")
     args = ap.parse_args()
+    cpu_bound = bind_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))),
+                          args.cpu_bind)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -848,10 +902,12 @@ def main():
             out = module(gt, dt_, s) if K == 3 else module(dt_, gt, s)
             out.backward(cot.to(out.dtype))
 
-        for _ in range(5):
+        # (10 untimed + >= 30 timed passes.  The leg is launch-rate-bound — ~215 us of host time per pass, 150 of it the autograd
+        #  engine's — so it reads what the host threads' placement allows: see bind_cpus)
+        for _ in range(10):
             fwd_bwd()
         torch.cuda.synchronize()
-        nt = max(10, args.steps // 8)
+        nt = max(30, args.steps // 8)
         t0t = time.perf_counter()
         for _ in range(nt):
             fwd_bwd()
@@ -912,7 +968,8 @@ def main():
             "config": {"workload": wl["name"], "batch_per_gpu": B_local, "H": wl["H"], "W": wl["W"], "K": K,
                        "prop_time": T, "guidance_channels": wl["C"], "sparse": bool(args.sparse),
                        "step": "prepare + %d propagation steps%s" % (T, "" if args.no_metrics else " + depth metrics (fused into the last launch)"),
-                       "plan": eff_plan, "hip_graph": bool(use_graph), "parallelism": "batch-shard x%d, metrics all-gather" % world},
+                       "plan": eff_plan, "hip_graph": bool(use_graph), "parallelism": "batch-shard x%d, metrics all-gather" % world,
+                       "host_cpu_bind": cpu_bound},
             "roofline": per_step if per_step is not None else (
                 dict(fused, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None)
                 if S == 1 else None),
@@ -929,7 +986,8 @@ def main():
             res["training_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(wl)
+                with full_affinity():
+                    res["cpu_baseline"] = cpu_baseline(wl)
             except Exception as e:  # pragma: no cover
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -26,6 +26,9 @@ std::atomic<int>& force_generic_flag() {
 
 // workgroups the any-geometry launches aim for (channel chunks / tap groups are split until there are that many): measured on
 // the C = 32 dilated row — 512 / 1024 / 2048 workgroups: forward 57 / 47 / 54 us; dL/dkernel with 1 / 2 tap groups: 58 / 88 us
+#ifndef CSPN_PAC_NT
+#define CSPN_PAC_NT 0          // developer A/B: 1 = non-temporal stores of the tiled kernels' results
+#endif
 #ifndef CSPN_PAC_WANT_WGS
 #define CSPN_PAC_WANT_WGS 1024
 #endif
@@ -306,6 +309,11 @@ __global__ __launch_bounds__(256, (K > 5 && (CB <= 4 || NBUF == 1) ? 2 : 1)) voi
     };
     auto store_dst = [&](int c, const float (&acc)[4]) {
         T* op = dst + ((size_t)b * a.C + c) * dplane + dpix;
+#if CSPN_PAC_NT & 1
+        if constexpr (std::is_same<T, float>::value) {
+            if (a.dst_vec) { const v4f v = {acc[0], acc[1], acc[2], acc[3]}; __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(op)); return; }
+        }
+#endif
         if (a.dst_vec) store_quad<T, true>(op, x0, a.dst_w, acc);
         else store_quad<T, false>(op, x0, a.dst_w, acc);
     };
