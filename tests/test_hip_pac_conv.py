@@ -201,6 +201,26 @@ def test_fuzz_stride2_register_kernels_and_generic(seed):
         assert nmax(gk, wgk) <= tol, (tag, scalar)
 
 
+def test_stride2_unaligned_tensors_take_the_generic_kernels():
+    """The register kernels need 16-byte aligned bases; a tensor that starts 4 bytes into its storage must still give the right
+    answer (the entry points fall back to the generic kernels instead of issuing misaligned 16-byte accesses)."""
+    torch.manual_seed(5)
+    B, C, H, W, K = 2, 3, 10, 16, 3
+    Ho, Wo = pac.output_size((H, W), K, 2, 1, 1)
+
+    def off1(shape):
+        n = int(np.prod(shape))
+        return torch.randn(n + 1, device=DEV)[1:].view(shape)
+    x, k, g = off1((B, C, H, W)), off1((B, 1, K, K, Ho, Wo)).mul_(0.3), off1((B, C, Ho, Wo))
+    assert x.data_ptr() % 16 and k.data_ptr() % 16 and g.data_ptr() % 16 and x.is_contiguous()
+    xa, ka = x.clone().requires_grad_(True), k.clone().requires_grad_(True)        # aligned copies: the register kernels
+    xu, ku = x.requires_grad_(True), k.requires_grad_(True)
+    oa = pac.conv2d(xa, ka, K, 2, 1, 1); oa.backward(g.clone())
+    ou = pac.conv2d(xu, ku, K, 2, 1, 1); ou.backward(g)
+    for a, b in ((oa, ou), (xa.grad, xu.grad), (ka.grad, ku.grad)):
+        assert float((a - b).abs().max() / a.abs().max()) <= 2e-6
+
+
 @pytest.mark.parametrize("C,CK,K,dt", [(32, 1, 3, torch.float32), (9, 9, 3, torch.float32), (16, 1, 5, torch.float32),
                                        (6, 6, 5, torch.float32), (12, 1, 3, torch.float16)])
 def test_stride2_full_frame_register_kernels_equal_generic(C, CK, K, dt):
