@@ -148,7 +148,10 @@ def bind_cpus(local_rank, local_world, mode):
     leg then depends on where they happen to land: the training-shaped leg read 213-217 us per pass in some processes and 265-290 us
     in others with IDENTICAL kernel times (rocprofv3: 86 + 61 + 60 us in every run) — bound to four cores it reads 213-217 us in
     every run, and the headline value gains ~2 % (same-box A/B, five alternating runs; tools/probes/r04_train_bimodal.sh).
-    What `numactl` / `taskset` in a launch script would do; --cpu-bind off leaves the mask alone."""
+    What `numactl` / `taskset` in a launch script would do; --cpu-bind off leaves the mask alone.  (The block is the rank's
+    share of the FIRST allowed cores on purpose: picking the idlest block of the moment — /proc/stat over 40 ms — was tried and
+    is worse, twice it chose cores 4-7 of a box and the leg read 600-720 us: idle cores sit in deep C-states and the autograd
+    engine's hand-offs pay their wake-up latency; cores 0-3 are kept awake by the system's own housekeeping.)"""
     global _ORIG_AFFINITY
     if mode == "off":
         return None
