@@ -163,3 +163,28 @@ def test_resident_plan_host_rules():
     assert F.resident_plan(24, 228, 304, 5, 0, 256, steps_per_phase=5) is not None      # a single phase may be odd
     assert F.resident_plan(24, 228, 304, 24, 0, 256, steps_per_phase=6)["steps_per_phase"] == 6
     assert F.resident_plan(4, 64, 30, 24, 0, 256) is None                               # W % 4 != 0
+
+
+def test_bench_cpu_binding_narrows_and_restores_the_affinity_mask():
+    """bench.py --cpu-bind auto: a rank's host threads go to its share of the first allowed cores; the CPU baseline leg gets the
+    whole mask back (full_affinity), and the reported host budget is the original one."""
+    import importlib.util
+    import os
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity on this platform")
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = os.sched_getaffinity(0)
+    try:
+        assert bench.bind_cpus(0, 1, "off") is None and os.sched_getaffinity(0) == before
+        mine = bench.bind_cpus(1, 2, "auto")
+        if len(before) >= 4:
+            k = 4 if len(before) >= 8 else len(before) // 2
+            assert mine == sorted(before)[k:2 * k] and os.sched_getaffinity(0) == set(mine)
+            assert bench.host_cpu_budget()["sched_affinity"] == len(before)
+            with bench.full_affinity():
+                assert os.sched_getaffinity(0) == before
+            assert os.sched_getaffinity(0) == set(mine)
+    finally:
+        os.sched_setaffinity(0, before)
