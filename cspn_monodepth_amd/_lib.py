@@ -15,12 +15,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "pac_conv2d.hip", "pac_conv2d_s2.hip", "cspn_unpool.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "cspn_debug.hip", "pac_conv2d.hip", "pac_conv2d_s2.hip", "cspn_unpool.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(CSRC, "cspnk_helpers.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
 CSPN_F32, CSPN_F16 = 0, 1
-ABI_VERSION = 9          # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
+ABI_VERSION = 10         # CSPN_ABI_VERSION of include/cspn_hip.h this host code was written against
 BLEND_NONE, BLEND_SPARSE, BLEND_PREMASK = 0, 1, 2
 
 # every symbol include/cspn_hip.h declares (tests check the .so exports all of them)
@@ -31,7 +31,7 @@ EXPORTS = (
     "cspnk_resident_plan", "cspnk_resident_workspace_bytes", "cspnk_forward_resident", "cspnk_forward_resident_history", "cspnk_transposed_resident",
     "cspn_grad_weights", "cspn3_grad_guidance", "cspn_pac_grad_guided", "cspn3_backward_tail",
     "cspn_pac_backward_tail", "cspn_metrics_accumulate",
-    "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward",
+    "cspn_pac_out_size", "cspn_pac_force_generic", "cspn_pac_conv2d", "cspn_pac_conv2d_grad_input", "cspn_pac_conv2d_grad_kernel", "cspn_pac_nd2col", "cspn_unpool2d", "cspn_unpool2d_backward", "cspn_debug_set_lds_poison",
 )
 
 
@@ -187,6 +187,7 @@ def _declare(lib):
     lib.cspn_pac_nd2col.argtypes = [vp, vp, ci, ci, ci, ci, ci, geom, vp]
     lib.cspn_unpool2d.argtypes = [vp, vp, ci, cl, ci, ci, ci, ci, ci, vp]
     lib.cspn_unpool2d_backward.argtypes = [vp, vp, ci, cl, ci, ci, ci, ci, ci, vp]
+    lib.cspn_debug_set_lds_poison.argtypes = [ci, ctypes.c_uint, ctypes.POINTER(ci)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("cspn_last_error", "cspn_propagate_workspace_bytes", "cspn3_resident_workspace_bytes",
@@ -208,6 +209,9 @@ def lib():
                 _lib = _declare(ctypes.CDLL(SO_PATH))
                 if _lib.cspn_abi_version() != ABI_VERSION:
                     raise RuntimeError("cspn_monodepth_amd: ABI version mismatch")
+                poison = os.environ.get("CSPN_DEBUG_LDS_POISON", "")      # debugging aid (include/cspn_hip.h): "nan" or a hex word
+                if poison and poison != "0":
+                    _lib.cspn_debug_set_lds_poison(1, 0x7fc00000 if poison in ("1", "nan") else int(poison, 16), None)
     return _lib
 
 

@@ -34,7 +34,24 @@ bool pac_s2_geometry(int kh, int kw, int sh, int sw, int ph, int pw, int dh, int
 int pac_s2_forward(const void* in, const void* kern, void* out, int dtype, int K, const PacS2Args& a, void* stream);
 int pac_s2_grad_input(const void* gout, const void* kern, void* gin, int dtype, int K, const PacS2Args& a, void* stream);
 int pac_s2_grad_kernel(const void* gout, const void* in, void* gk, int dtype, int K, const PacS2Args& a, void* stream);
+// cspn_debug.hip: the poisoned-LDS debugging aid (include/cspn_hip.h: cspn_debug_set_lds_poison)
+extern int g_lds_poison_on;
+void lds_poison(hipStream_t st);
 }  // namespace cspn_detail
+
+// Every launch of the library goes through this hook: with the poisoned-LDS switch on, the whole LDS of every CU is filled with
+// a pattern in front of the kernel (a kernel that reads LDS it never wrote then shows it).  Off: one predictable branch.
+#define CSPN_PRELAUNCH(st)                                                                \
+    do {                                                                                  \
+        if (__builtin_expect(cspn_detail::g_lds_poison_on, 0)) cspn_detail::lds_poison(st);   \
+    } while (0)
+#define CSPN_PRE(st) (__builtin_expect(cspn_detail::g_lds_poison_on, 0) ? cspn_detail::lds_poison(st) : (void)0)   // expression form: `CSPN_PRE(st), kernel<<<...>>>(...)`
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, lds, st, ...)                                \
+    do {                                                                                  \
+        CSPN_PRELAUNCH(st);                                                               \
+        hipLaunchKernelGGLInternal((kern), (grid), (block), (lds), (st), __VA_ARGS__);    \
+    } while (0)
 
 namespace {
 

@@ -473,9 +473,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
     // waits for the whole stream — after the weight arithmetic, which consumes the stream as it arrives, that wait is free
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        const int r = r0 + i;
         const bool ok = (in_img >> i) & 1u;
-        if (BLEND && r < wr) {
+        // EVERY slot of the thread is written, also those of rows past the region (r0 + i >= wr: m = 0 there).  The step body
+        // computes those rows too (zero taps) and a CLEAN instance trusts the result to be exactly 0 — it is the lower neighbour
+        // of the region's last row, i.e. the zero padding below the image for a bottom-edge tile — so the blend term it adds must
+        // not be whatever the previous kernel on this CU left in LDS (round 5: the root cause of the one-off bit mismatch at
+        // KITTI B = 8 with sparse depth, the one production shape with wr % NQ != 0; tests: the poisoned-LDS runs).
+        if (BLEND) {
             // (1-m) u + m d0  ==  sum_j ((1-m) w_j) d_j + m d0 with 1-m in {0,1,2}: exact, so bit-identical (CSPN_new.py:90)
             const float4 m = make_float4(ok ? sgnf(mraw[i].x) : 0.f, ok ? sgnf(mraw[i].y) : 0.f, ok ? sgnf(mraw[i].z) : 0.f, ok ? sgnf(mraw[i].w) : 0.f);
             const float omq[4] = {1.f - m.x, 1.f - m.y, 1.f - m.z, 1.f - m.w};

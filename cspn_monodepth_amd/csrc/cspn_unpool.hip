@@ -100,16 +100,16 @@ int cspn_unpool2d(const void* input, void* out, int dtype, long planes, int H, i
         const unsigned total = (unsigned)(planes * ((oH + 1) / 2) * oWQ);
         const dim3 grid((total + 255u) / 256u), block(256);
         if (dtype == CSPN_F16)
-            unpool_fwd_s2<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(input), static_cast<__half*>(out), H, W, oH, oW, oWQ, total);
+            CSPN_PRE(st), unpool_fwd_s2<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(input), static_cast<__half*>(out), H, W, oH, oW, oWQ, total);
         else
-            unpool_fwd_s2<float><<<grid, block, 0, st>>>(static_cast<const float*>(input), static_cast<float*>(out), H, W, oH, oW, oWQ, total);
+            CSPN_PRE(st), unpool_fwd_s2<float><<<grid, block, 0, st>>>(static_cast<const float*>(input), static_cast<float*>(out), H, W, oH, oW, oWQ, total);
     } else {
         const unsigned total = (unsigned)(planes * oH * oWQ);
         const dim3 grid((total + 255u) / 256u), block(256);
         if (dtype == CSPN_F16)
-            unpool_fwd<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(input), static_cast<__half*>(out), H, W, scale, oH, oW, oWQ, total, vec);
+            CSPN_PRE(st), unpool_fwd<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(input), static_cast<__half*>(out), H, W, scale, oH, oW, oWQ, total, vec);
         else
-            unpool_fwd<float><<<grid, block, 0, st>>>(static_cast<const float*>(input), static_cast<float*>(out), H, W, scale, oH, oW, oWQ, total, vec);
+            CSPN_PRE(st), unpool_fwd<float><<<grid, block, 0, st>>>(static_cast<const float*>(input), static_cast<float*>(out), H, W, scale, oH, oW, oWQ, total, vec);
     }
     HIP_OK(hipGetLastError());
     return 1;
@@ -123,9 +123,9 @@ int cspn_unpool2d_backward(const void* grad_out, void* grad_input, int dtype, lo
     const dim3 grid((total + 255u) / 256u), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == CSPN_F16)
-        unpool_bwd<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(grad_out), static_cast<__half*>(grad_input), H, W, scale, oH, oW, total);
+        CSPN_PRE(st), unpool_bwd<__half><<<grid, block, 0, st>>>(static_cast<const __half*>(grad_out), static_cast<__half*>(grad_input), H, W, scale, oH, oW, total);
     else
-        unpool_bwd<float><<<grid, block, 0, st>>>(static_cast<const float*>(grad_out), static_cast<float*>(grad_input), H, W, scale, oH, oW, total);
+        CSPN_PRE(st), unpool_bwd<float><<<grid, block, 0, st>>>(static_cast<const float*>(grad_out), static_cast<float*>(grad_input), H, W, scale, oH, oW, total);
     HIP_OK(hipGetLastError());
     return 1;
 }

@@ -1313,8 +1313,8 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
             t.cchunk = ceil_div(a.C, std::max(nchunk8, 1));
             t.lin_tiles = tiles8; t.lin_chunks = ceil_div(a.C, t.cchunk);
             const dim3 grid8 = lin_grid(tiles8, t.lin_chunks, a.B), block8(256);
-            if (a.CK == 1 && t.cchunk > 1) pac_conv2d_tiled_h8<K, true><<<grid8, block8, 0, st>>>(src, kern, dst, t);
-            else pac_conv2d_tiled_h8<K, false><<<grid8, block8, 0, st>>>(src, kern, dst, t);
+            if (a.CK == 1 && t.cchunk > 1) CSPN_PRE(st), pac_conv2d_tiled_h8<K, true><<<grid8, block8, 0, st>>>(src, kern, dst, t);
+            else CSPN_PRE(st), pac_conv2d_tiled_h8<K, false><<<grid8, block8, 0, st>>>(src, kern, dst, t);
             HIP_OK(hipGetLastError());
             return 1;
         }
@@ -1338,18 +1338,18 @@ int launch_tiled(const T* src, const T* kern, T* dst, const ConvArgs& a, int dst
             t.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk8, 1)), 8) * 8;
             t.lin_chunks = ceil_div(a.C, t.cchunk);
             const dim3 grid8 = lin_grid(tiles, t.lin_chunks, a.B);
-            if (t.cchunk <= 8) pac_conv2d_tiled<T, K, false, 8, TRANSPOSED, 1><<<grid8, block, 0, st>>>(src, kern, dst, t);
-            else pac_conv2d_tiled<T, K, false, 8, TRANSPOSED><<<grid8, block, 0, st>>>(src, kern, dst, t);
+            if (t.cchunk <= 8) CSPN_PRE(st), pac_conv2d_tiled<T, K, false, 8, TRANSPOSED, 1><<<grid8, block, 0, st>>>(src, kern, dst, t);
+            else CSPN_PRE(st), pac_conv2d_tiled<T, K, false, 8, TRANSPOSED><<<grid8, block, 0, st>>>(src, kern, dst, t);
             HIP_OK(hipGetLastError());
             return 1;
         }
     }
     if (t.cchunk == 1) {
-        if (hoist) pac_conv2d_tiled<T, K, CAN_HOIST, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
-        else pac_conv2d_tiled<T, K, false, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
+        if (hoist) CSPN_PRE(st), pac_conv2d_tiled<T, K, CAN_HOIST, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
+        else CSPN_PRE(st), pac_conv2d_tiled<T, K, false, 1, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
     } else {
-        if (hoist) pac_conv2d_tiled<T, K, CAN_HOIST, CC, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
-        else pac_conv2d_tiled<T, K, false, CC, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
+        if (hoist) CSPN_PRE(st), pac_conv2d_tiled<T, K, CAN_HOIST, CC, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
+        else CSPN_PRE(st), pac_conv2d_tiled<T, K, false, CC, TRANSPOSED><<<grid, block, 0, st>>>(src, kern, dst, t);
     }
     HIP_OK(hipGetLastError());
     return 1;
@@ -1394,9 +1394,9 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
             a.lin_tiles = tiles; a.lin_chunks = ceil_div(a.C, a.cchunk);
             const dim3 grid = lin_grid(tiles, a.lin_chunks, a.B), block(256);
             const size_t lds = (size_t)cb * psz * sizeof(float);
-            if (shared && a.kh * a.kw <= 9) pac_conv2d_fwd_tiled_any<T, true, false, true><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
-            else if (shared) pac_conv2d_fwd_tiled_any<T, true, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
-            else pac_conv2d_fwd_tiled_any<T, false, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            if (shared && a.kh * a.kw <= 9) CSPN_PRE(st), pac_conv2d_fwd_tiled_any<T, true, false, true><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else if (shared) CSPN_PRE(st), pac_conv2d_fwd_tiled_any<T, true, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else CSPN_PRE(st), pac_conv2d_fwd_tiled_any<T, false, false, false><<<grid, block, lds, st>>>(i, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
             HIP_OK(hipGetLastError());
             return 1;
         }
@@ -1404,10 +1404,10 @@ int conv_forward_typed(const void* in, const void* kern, void* out, ConvArgs a, 
     const int gx = ceil_div(a.Ho * a.WQ, 256);
     a.cchunk = channel_chunk(a.C, (size_t)gx * a.B);
     const dim3 grid(gx, ceil_div(a.C, a.cchunk), a.B), block(256);
-    if (a.vec && shared) pac_conv2d_fwd<T, true, true><<<grid, block, 0, st>>>(i, k, o, a);
-    else if (a.vec) pac_conv2d_fwd<T, true, false><<<grid, block, 0, st>>>(i, k, o, a);
-    else if (shared) pac_conv2d_fwd<T, false, true><<<grid, block, 0, st>>>(i, k, o, a);
-    else pac_conv2d_fwd<T, false, false><<<grid, block, 0, st>>>(i, k, o, a);
+    if (a.vec && shared) CSPN_PRE(st), pac_conv2d_fwd<T, true, true><<<grid, block, 0, st>>>(i, k, o, a);
+    else if (a.vec) CSPN_PRE(st), pac_conv2d_fwd<T, true, false><<<grid, block, 0, st>>>(i, k, o, a);
+    else if (shared) CSPN_PRE(st), pac_conv2d_fwd<T, false, true><<<grid, block, 0, st>>>(i, k, o, a);
+    else CSPN_PRE(st), pac_conv2d_fwd<T, false, false><<<grid, block, 0, st>>>(i, k, o, a);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -1429,7 +1429,7 @@ int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
             const int nchunk = (int)std::min<size_t>((4096 + (size_t)tiles8 * a.B - 1) / ((size_t)tiles8 * a.B), (size_t)a.C);
             t.cchunk = ceil_div(a.C, std::max(nchunk, 1));
             const dim3 grid8(tiles8, ceil_div(a.C, t.cchunk), a.B), block8(256);
-            pac_conv2d_gk_h8<K><<<grid8, block8, 0, st>>>(g, in, gk, t);
+            CSPN_PRE(st), pac_conv2d_gk_h8<K><<<grid8, block8, 0, st>>>(g, in, gk, t);
             HIP_OK(hipGetLastError());
             return 1;
         }
@@ -1449,11 +1449,11 @@ int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
             t.cchunk = ceil_div(a.C, nchunk);
             const dim3 grid(tiles, ceil_div(a.C, t.cchunk), a.B), block(256);
             if (a.CK == 1) {
-                if (a.C == 1) pac_conv2d_gk_window<T, K, true, 1><<<grid, block, 0, st>>>(g, in, gk, t);
-                else pac_conv2d_gk_window<T, K, true, CC><<<grid, block, 0, st>>>(g, in, gk, t);
+                if (a.C == 1) CSPN_PRE(st), pac_conv2d_gk_window<T, K, true, 1><<<grid, block, 0, st>>>(g, in, gk, t);
+                else CSPN_PRE(st), pac_conv2d_gk_window<T, K, true, CC><<<grid, block, 0, st>>>(g, in, gk, t);
             } else {
-                if (t.cchunk == 1) pac_conv2d_gk_window<T, K, false, 1><<<grid, block, 0, st>>>(g, in, gk, t);
-                else pac_conv2d_gk_window<T, K, false, CC><<<grid, block, 0, st>>>(g, in, gk, t);
+                if (t.cchunk == 1) CSPN_PRE(st), pac_conv2d_gk_window<T, K, false, 1><<<grid, block, 0, st>>>(g, in, gk, t);
+                else CSPN_PRE(st), pac_conv2d_gk_window<T, K, false, CC><<<grid, block, 0, st>>>(g, in, gk, t);
             }
             HIP_OK(hipGetLastError());
             return 1;
@@ -1473,14 +1473,14 @@ int conv_gk_tiled(const T* g, const T* in, T* gk, ConvArgs a, hipStream_t st) {
             const dim3 gridw(tiles, 1, a.B), blockw(256);
             // one channel per batch: 247 VGPRs, two wavefronts per SIMD (two channels: 256 + spills to AGPRs, one wavefront —
             // 67.8 vs 52.3 us; the tap-row split: 125.9 us)
-            pac_conv2d_gk_window<T, K, true, 1><<<gridw, blockw, 0, st>>>(g, in, gk, t);
+            CSPN_PRE(st), pac_conv2d_gk_window<T, K, true, 1><<<gridw, blockw, 0, st>>>(g, in, gk, t);
             HIP_OK(hipGetLastError());
             return 1;
         }
     }
     const dim3 grid(tiles, K, a.B), block(256);
-    if (a.CK == 1) pac_conv2d_gk_tiled<T, K, true><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
-    else pac_conv2d_gk_tiled<T, K, false><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
+    if (a.CK == 1) CSPN_PRE(st), pac_conv2d_gk_tiled<T, K, true><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
+    else CSPN_PRE(st), pac_conv2d_gk_tiled<T, K, false><<<grid, block, 0, st>>>(g, in, gk, a, tiles_x);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -1520,12 +1520,12 @@ int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStr
                 const int want_groups = (int)std::min<size_t>((size_t)ntap, (ANY_WANT_WGS_GK + have - 1) / have);
                 const int tpg = std::max(1, std::min(NTM, ceil_div(ntap, std::max(want_groups, 1))));
                 const dim3 grid(tiles, ceil_div(ntap, tpg), a.B), block(256);
-                pac_conv2d_gk_any<T, true, NTM><<<grid, block, lds, st>>>(g, i, o, a, tiles_x, (int)RWl, (int)RHl, cb, tpg);
+                CSPN_PRE(st), pac_conv2d_gk_any<T, true, NTM><<<grid, block, lds, st>>>(g, i, o, a, tiles_x, (int)RWl, (int)RHl, cb, tpg);
             } else {
                 int nchunk = (int)std::min<size_t>((1024 + have - 1) / have, (size_t)ceil_div(a.C, cb));
                 a.cchunk = ceil_div(ceil_div(a.C, std::max(nchunk, 1)), cb) * cb;
                 const dim3 grid(tiles, ceil_div(a.C, a.cchunk), a.B), block(256);
-                pac_conv2d_gk_any<T, false, NTM><<<grid, block, lds, st>>>(g, i, o, a, tiles_x, (int)RWl, (int)RHl, cb, 0);
+                CSPN_PRE(st), pac_conv2d_gk_any<T, false, NTM><<<grid, block, lds, st>>>(g, i, o, a, tiles_x, (int)RWl, (int)RHl, cb, 0);
             }
             HIP_OK(hipGetLastError());
             return 1;
@@ -1536,10 +1536,10 @@ int conv_gk_typed(const void* gout, const void* in, void* gk, ConvArgs a, hipStr
     const T* i = static_cast<const T*>(in);
     T* o = static_cast<T*>(gk);
     const bool shared = a.CK == 1;
-    if (a.vec && shared) pac_conv2d_gk<T, true, true><<<grid, block, 0, st>>>(g, i, o, a);
-    else if (a.vec) pac_conv2d_gk<T, true, false><<<grid, block, 0, st>>>(g, i, o, a);
-    else if (shared) pac_conv2d_gk<T, false, true><<<grid, block, 0, st>>>(g, i, o, a);
-    else pac_conv2d_gk<T, false, false><<<grid, block, 0, st>>>(g, i, o, a);
+    if (a.vec && shared) CSPN_PRE(st), pac_conv2d_gk<T, true, true><<<grid, block, 0, st>>>(g, i, o, a);
+    else if (a.vec) CSPN_PRE(st), pac_conv2d_gk<T, true, false><<<grid, block, 0, st>>>(g, i, o, a);
+    else if (shared) CSPN_PRE(st), pac_conv2d_gk<T, false, true><<<grid, block, 0, st>>>(g, i, o, a);
+    else CSPN_PRE(st), pac_conv2d_gk<T, false, false><<<grid, block, 0, st>>>(g, i, o, a);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -1571,9 +1571,9 @@ int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int
             const T* g = static_cast<const T*>(gout);
             const T* k = static_cast<const T*>(kern);
             T* o = static_cast<T*>(gin);
-            if (a.CK == 1 && a.kh * a.kw <= 9) pac_conv2d_fwd_tiled_any<T, true, true, true><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
-            else if (a.CK == 1) pac_conv2d_fwd_tiled_any<T, true, true, false><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
-            else pac_conv2d_fwd_tiled_any<T, false, true, false><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            if (a.CK == 1 && a.kh * a.kw <= 9) CSPN_PRE(st), pac_conv2d_fwd_tiled_any<T, true, true, true><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else if (a.CK == 1) CSPN_PRE(st), pac_conv2d_fwd_tiled_any<T, true, true, false><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
+            else CSPN_PRE(st), pac_conv2d_fwd_tiled_any<T, false, true, false><<<grid, block, lds, st>>>(g, k, o, a, tiles_x, (int)RWl, (int)RHl, cb);
             HIP_OK(hipGetLastError());
             return 1;
         }
@@ -1586,10 +1586,10 @@ int conv_gi_typed(const void* gout, const void* kern, void* gin, ConvArgs a, int
     const T* k = static_cast<const T*>(kern);
     T* o = static_cast<T*>(gin);
     const bool shared = a.CK == 1, unit = a.sh == 1 && a.sw == 1;
-    if (shared && unit) pac_conv2d_gi<T, true, true><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
-    else if (shared) pac_conv2d_gi<T, true, false><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
-    else if (unit) pac_conv2d_gi<T, false, true><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
-    else pac_conv2d_gi<T, false, false><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    if (shared && unit) CSPN_PRE(st), pac_conv2d_gi<T, true, true><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    else if (shared) CSPN_PRE(st), pac_conv2d_gi<T, true, false><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    else if (unit) CSPN_PRE(st), pac_conv2d_gi<T, false, true><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
+    else CSPN_PRE(st), pac_conv2d_gi<T, false, false><<<grid, block, 0, st>>>(g, k, o, a, in_wq, in_vec);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -1598,8 +1598,8 @@ template <typename T>
 int nd2col_typed(const void* in, void* cols, ConvArgs a, hipStream_t st) {
     if ((long)a.B * a.C > 65535) return fail("cspn_pac_nd2col: B*C=%ld exceeds the grid limit 65535", (long)a.B * a.C);
     const dim3 grid(ceil_div(a.Ho * a.WQ, 256), a.kh * a.kw, a.B * a.C), block(256);
-    if (a.vec) pac_nd2col_kernel<T, true><<<grid, block, 0, st>>>(static_cast<const T*>(in), static_cast<T*>(cols), a);
-    else pac_nd2col_kernel<T, false><<<grid, block, 0, st>>>(static_cast<const T*>(in), static_cast<T*>(cols), a);
+    if (a.vec) CSPN_PRE(st), pac_nd2col_kernel<T, true><<<grid, block, 0, st>>>(static_cast<const T*>(in), static_cast<T*>(cols), a);
+    else CSPN_PRE(st), pac_nd2col_kernel<T, false><<<grid, block, 0, st>>>(static_cast<const T*>(in), static_cast<T*>(cols), a);
     HIP_OK(hipGetLastError());
     return 1;
 }

@@ -474,8 +474,8 @@ int forward_k(const void* in_, const void* kern_, void* out_, PacS2Args a, hipSt
     const int gx = ceil_div(a.Ho * a.WQ, 256);
     a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, CSPN_S2_WANT);
     const dim3 grid = chunked_grid(a, gx), block(256);
-    if (a.CK == 1) pac_s2_fwd<T, K, true, CB><<<grid, block, 0, st>>>(in, kern, out, a);
-    else pac_s2_fwd<T, K, false, CB><<<grid, block, 0, st>>>(in, kern, out, a);
+    if (a.CK == 1) CSPN_PRE(st), pac_s2_fwd<T, K, true, CB><<<grid, block, 0, st>>>(in, kern, out, a);
+    else CSPN_PRE(st), pac_s2_fwd<T, K, false, CB><<<grid, block, 0, st>>>(in, kern, out, a);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -489,8 +489,8 @@ int grad_input_k(const void* gout_, const void* kern_, void* gin_, PacS2Args a, 
     const int gx = ceil_div(a.Ho * a.WQ, 256);
     a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, CSPN_S2_WANT);
     const dim3 grid = chunked_grid(a, gx), block(256);
-    if (a.CK == 1) pac_s2_gi<T, K, true, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
-    else pac_s2_gi<T, K, false, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
+    if (a.CK == 1) CSPN_PRE(st), pac_s2_gi<T, K, true, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
+    else CSPN_PRE(st), pac_s2_gi<T, K, false, CB><<<grid, block, 0, st>>>(gout, kern, gin, a);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -503,14 +503,14 @@ int grad_kernel_k(const void* gout_, const void* in_, void* gk_, PacS2Args a, hi
     if (a.CK == 1) {
         constexpr int NW = K == 3 ? 4 : 2, CB = K == 3 ? 2 : 1;
         const dim3 grid(ceil_div(a.Ho * a.WQ, 64), 1, a.B), block(64 * NW);
-        if (a.C == 1) pac_s2_gk_shared<T, K, 1, 1><<<grid, dim3(64), 0, st>>>(gout, in, gk, a);
-        else pac_s2_gk_shared<T, K, NW, CB><<<grid, block, 0, st>>>(gout, in, gk, a);
+        if (a.C == 1) CSPN_PRE(st), pac_s2_gk_shared<T, K, 1, 1><<<grid, dim3(64), 0, st>>>(gout, in, gk, a);
+        else CSPN_PRE(st), pac_s2_gk_shared<T, K, NW, CB><<<grid, block, 0, st>>>(gout, in, gk, a);
     } else {
         constexpr int CB = K == 3 ? 2 : 1;
         const int gx = ceil_div(a.Ho * a.WQ, 256);
         a.cchunk = chunk_for(a.C, (size_t)gx * a.B, CB, CSPN_S2_WANT);
         const dim3 grid = chunked_grid(a, gx), block(256);
-        pac_s2_gk_perch<T, K, CB><<<grid, block, 0, st>>>(gout, in, gk, a);
+        CSPN_PRE(st), pac_s2_gk_perch<T, K, CB><<<grid, block, 0, st>>>(gout, in, gk, a);
     }
     HIP_OK(hipGetLastError());
     return 1;

@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CSPN_ABI_VERSION 9
+#define CSPN_ABI_VERSION 10
 
 typedef void* cspn_stream_t; /* hipStream_t */
 
@@ -389,6 +389,17 @@ int cspn_unpool2d(const void* input, void* out, int dtype, long planes, int H, i
                   cspn_stream_t stream);
 int cspn_unpool2d_backward(const void* grad_out, void* grad_input, int dtype, long planes, int H, int W, int scale,
                            int oH, int oW, cspn_stream_t stream);
+
+/* ---- debugging aid: poisoned LDS (round 5) --------------------------------------------------- *
+ * A kernel does not get a cleared LDS: it inherits what the previous workgroup on the CU left there, so a kernel that reads an
+ * LDS word it never wrote returns results that depend on what ran before it.  (That was the root cause of the one bit mismatch
+ * ever seen on the default path: cspn3_resident's blended CLEAN instances added a never-written private slot to the rows past
+ * the region, and for a bottom-edge tile that sum is the zero padding below the image — DESIGN.md §4.1b.)
+ * enabled != 0: from now on EVERY kernel this library launches is preceded, on the same stream, by a fill of all 160 KB of LDS
+ * of every CU with `pattern` (0x7fc00000 = NaN makes any such read visible in the result).  Process-wide, off by default,
+ * meant for test runs (tests/: CSPN_DEBUG_LDS_POISON=nan runs the whole GPU suite that way); costs one predictable host branch
+ * per launch when off.  Results of a correct kernel are unchanged.  *previous_or_null receives the previous setting. */
+int cspn_debug_set_lds_poison(int enabled, unsigned pattern, int* previous_or_null);
 
 #ifdef __cplusplus
 }

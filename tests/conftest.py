@@ -94,3 +94,87 @@ def occupy_lib():
     lib.occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
     lib.occupy.restype = ctypes.c_int
     return lib
+
+
+def bits_equal(a, b, **ctx):
+    """torch.equal(a, b) — and on a mismatch a dump of WHICH elements differ under gpurun_out/mismatch/ (VERDICT r4 next #1a: the
+    one bit mismatch round 4 ever saw left nothing to analyse).  The dump holds the differing index set (per dimension, the first
+    elements with both values), the host protocol's state (flag sequence number, workspace pointers, fallbacks) and, when
+    the tensors are [B,(1,)H,W] planes of a shape with a resident tiling, the tile / row-in-tile / column-in-tile of every differing
+    pixel of the first image concerned."""
+    import json
+    import torch
+    if a.shape == b.shape and torch.equal(a, b):
+        return True
+    try:
+        from cspn_monodepth_amd import functional as F
+        rec = dict(test=os.environ.get("PYTEST_CURRENT_TEST", "?"), shape_a=list(a.shape), shape_b=list(b.shape), dtype=str(a.dtype),
+                   ctx={k: (v if isinstance(v, (int, float, str, bool, type(None), list, tuple, dict)) else repr(v)) for k, v in ctx.items()},
+                   fallbacks=F.resident_fallbacks(), resident_mode=F._RESIDENT_MODE)
+        for idx, st in F._RES.items():
+            rec["device%d" % idx] = dict(seq=st["seq"], host_err=[int(v) for v in st["host_err_np"]], dirty=st["dirty"],
+                                         journal=len(st["journal"]), last_seq=st.get("last_seq"),
+                                         workspaces={str(k): hex(w.data_ptr()) for k, w in st["work"].items()})
+        if a.shape == b.shape:
+            af, bf = a.detach(), b.detach()
+            diff = ~((af == bf) | (torch.isnan(af) & torch.isnan(bf))) if af.is_floating_point() else (af != bf)
+            only_nan_vs_nan = bool((torch.isnan(af) & torch.isnan(bf)).any()) if af.is_floating_point() else False
+            idx = diff.nonzero().cpu().numpy()
+            rec.update(n_diff=int(idx.shape[0]), nan_in_a=int(torch.isnan(af).sum()) if af.is_floating_point() else 0,
+                       nan_in_b=int(torch.isnan(bf).sum()) if bf.is_floating_point() else 0, nan_at_same_places=only_nan_vs_nan)
+            if idx.shape[0]:
+                per_dim = []
+                for d in range(idx.shape[1]):
+                    u = np.unique(idx[:, d])
+                    per_dim.append(dict(min=int(u.min()), max=int(u.max()), count=int(u.size), values=[int(v) for v in u[:96]]))
+                rec["per_dim"] = per_dim
+                ac, bc = af.cpu().numpy(), bf.cpu().numpy()
+                rec["first"] = [dict(index=[int(v) for v in i], a=repr(ac[tuple(i)]), b=repr(bc[tuple(i)])) for i in idx[:48]]
+                if a.dim() in (3, 4) and "T" in ctx:
+                    B, H, W = a.shape[0], a.shape[-2], a.shape[-1]
+                    rp = F.resident_plan(B, H, W, int(ctx["T"]), int(bool(ctx.get("sparse"))), 256)
+                    if rp is not None:
+                        rec["resident_plan"] = {k: rp[k] for k in ("steps_per_phase", "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread", "images_per_launch", "launches")}
+                        img = int(idx[0, 0])
+                        sel = idx[idx[:, 0] == img]
+                        ys, xs = sel[:, -2], sel[:, -1]
+                        tiles = {}
+                        for y, x in zip(ys[:20000], xs[:20000]):
+                            key = "%d,%d" % (y // rp["tile_h"], x // rp["tile_w"])
+                            t = tiles.setdefault(key, dict(n=0, row_in_tile=[10 ** 9, -1], col_in_tile=[10 ** 9, -1]))
+                            t["n"] += 1
+                            ry, rx = int(y % rp["tile_h"]), int(x % rp["tile_w"])
+                            t["row_in_tile"] = [min(t["row_in_tile"][0], ry), max(t["row_in_tile"][1], ry)]
+                            t["col_in_tile"] = [min(t["col_in_tile"][0], rx), max(t["col_in_tile"][1], rx)]
+                        rec["image"] = img
+                        rec["launch_of_image"] = img // max(rp["images_per_launch"], 1)
+                        rec["tiles_ty_tx"] = tiles
+        out_dir = os.path.join(ROOT, "gpurun_out", "mismatch")
+        os.makedirs(out_dir, exist_ok=True)
+        name = "".join(c if c.isalnum() or c in "-_." else "_" for c in rec["test"])[-150:]
+        n = len(glob.glob(os.path.join(out_dir, name + "*.json")))
+        with open(os.path.join(out_dir, "%s.%d.json" % (name, n)), "w") as fh:
+            json.dump(rec, fh, indent=1)
+        print("bits_equal: MISMATCH dumped to gpurun_out/mismatch/%s.%d.json (%s differing)" % (name, n, rec.get("n_diff", "shape")))
+    except Exception as exc:       # noqa: BLE001 — the dump must never hide the assertion it serves
+        print("bits_equal: mismatch (dump failed: %r)" % (exc,))
+    return False
+
+
+class lds_poison(object):
+    """with lds_poison(): every kernel the engine launches is preceded by a NaN fill of the whole LDS of every CU
+    (include/cspn_hip.h: cspn_debug_set_lds_poison) — a kernel that reads LDS it never wrote then shows it in its result."""
+
+    def __init__(self, pattern=0x7fc00000):
+        self.pattern = pattern
+
+    def __enter__(self):
+        import ctypes
+        from cspn_monodepth_amd import _lib
+        self.prev = ctypes.c_int(0)
+        _lib.check(_lib.lib().cspn_debug_set_lds_poison(1, self.pattern, ctypes.byref(self.prev)), "cspn_debug_set_lds_poison")
+
+    def __exit__(self, *exc):
+        from cspn_monodepth_amd import _lib
+        _lib.lib().cspn_debug_set_lds_poison(self.prev.value, self.pattern, None)
+        return False

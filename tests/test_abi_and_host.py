@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.EXPORTS), (declared, _lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.lib().cspn_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib().cspn_abi_version() == _lib.ABI_VERSION == 10
     assert _lib.lib().cspn_propagate_workspace_bytes(24, 228, 304, 24, _lib.CSPN_F32, 0) == 2 * 24 * 228 * 304 * 4
     assert _lib.lib().cspn_propagate_workspace_bytes(24, 228, 304, 24, _lib.CSPN_F32, 1) == 0
 

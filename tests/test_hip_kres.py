@@ -12,7 +12,7 @@ import torch
 
 import cspn_monodepth_amd as pkg
 from cspn_monodepth_amd import functional as F
-from conftest import golden_names, load_golden, rmse
+from conftest import bits_equal, golden_names, load_golden, rmse
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -80,7 +80,7 @@ def test_resident_equals_multi_launch_bit_for_bit(K, B, H, W, T, S, sparse, stat
     torch.cuda.synchronize()
     F.ensure_resident_ok()
     assert out.dtype == ref.dtype == sdt
-    assert torch.equal(out, ref[:, 0]), float((out.float() - ref[:, 0].float()).abs().max())
+    assert bits_equal(out, ref[:, 0]), float((out.float() - ref[:, 0].float()).abs().max())
     if B * H * W <= 3 * 228 * 304:
         f32 = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)      # noqa: E731
         want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)[:, 0]
@@ -106,8 +106,8 @@ def test_768_thread_workgroups_give_the_same_bits(K, B, H, W, T, S, sparse, c_or
         b_ = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S, threads=512,
                                     step_form=F.STEP_FMA)
     F.ensure_resident_ok()
-    assert torch.equal(a, b_)
-    assert torch.equal(a, multi_launch(xt, gt, st, T, S, None)[:, 0])
+    assert bits_equal(a, b_)
+    assert bits_equal(a, multi_launch(xt, gt, st, T, S, None)[:, 0])
 
 
 F32_SHAPES = [(3, 24, 228, 304, 24, 8), (3, 3, 228, 304, 24, 6), (3, 2, 37, 40, 6, 4), (3, 1, 352, 1216, 24, 8), (5, 2, 40, 64, 12, 4),
@@ -128,7 +128,7 @@ def test_fp32_guidance_resident_equals_multi_launch(K, B, H, W, T, S, sparse, c_
     with torch.no_grad():
         out = F.pac_forward_resident(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T, steps_per_phase=S)
     F.ensure_resident_ok()
-    assert out.dtype == torch.float32 and torch.equal(out, ref[:, 0]), float((out - ref[:, 0]).abs().max())
+    assert out.dtype == torch.float32 and bits_equal(out, ref[:, 0]), float((out - ref[:, 0]).abs().max())
     if B * H * W <= 3 * 228 * 304:
         want = c_oracle.pac_forward(x, gd, s, T)[:, 0]
         o = out.cpu().numpy()
@@ -148,7 +148,7 @@ def test_unet_ours_configuration_takes_the_resident_path(c_oracle):
         out = m(xt, gt, sparse_depth=st)
     ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], None)
     F.ensure_resident_ok()
-    assert torch.equal(out, ref)
+    assert bits_equal(out, ref)
 
 
 @pytest.mark.parametrize("state", [None, "reference"], ids=["state16", "reference"])
@@ -174,11 +174,11 @@ def test_module_takes_the_resident_path_at_config3(state, c_oracle):
         with torch.no_grad(), resident("on"):
             F.set_kres_step_form("fma")
             try:
-                assert torch.equal(m(xt, gt, sparse_depth=st), ref)
+                assert bits_equal(m(xt, gt, sparse_depth=st), ref)
             finally:
                 F.set_kres_step_form("auto")
     else:
-        assert torch.equal(out, ref)
+        assert bits_equal(out, ref)
     f32 = lambda a: a.astype(np.float16).astype(np.float32)               # noqa: E731
     want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)
     scale = float(np.abs(want).max())
@@ -202,7 +202,7 @@ def test_scored_resident_forward(c_oracle):
         ref = m(xt, gt)
         sums, _ = ev.all_gather_metric_sums(acc)
         want = ev.metric_sums(ref, tt)
-    assert torch.equal(out, ref)
+    assert bits_equal(out, ref)
     assert np.allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
     assert ev.finalize_metrics(sums)["count"] == int((tgt > 0).sum())
 
@@ -241,10 +241,10 @@ def test_resident_timeout_is_repaired_in_place(c_oracle):
             n = F.resident_fallbacks()
             F.ensure_resident_ok()
             assert F.resident_fallbacks() == n + 1
-            assert torch.equal(out, ref[:, 0])                         # the multi-launch schedule's bits (S = 4: the default plan)
+            assert bits_equal(out, ref[:, 0])                         # the multi-launch schedule's bits (S = 4: the default plan)
             good = F.pac_forward_resident(gt, xt, None, T, step_form=form)
             if form == F.STEP_FMA:
-                assert torch.equal(good, ref[:, 0])
+                assert bits_equal(good, ref[:, 0])
             else:
                 assert float((good.float() - ref[:, 0].float()).abs().max()) <= 4e-3 * float(ref.float().abs().max())
     F.ensure_resident_ok()
@@ -281,7 +281,7 @@ def test_random_shapes_against_the_oracle_and_the_multi_launch_schedule(seed, c_
             out = F.pac_forward_resident(gt, xt[:, 0].to(sdt).contiguous(), None if st is None else st[:, 0].to(sdt).contiguous(), T,
                                          steps_per_phase=S, threads=threads, step_form=F.STEP_FMA)
         case = (K, f32, B, H, W, T, S, threads, sparse, str(state), rp["tiles_x"], rp["tiles_y"], rp["quads_per_thread"])
-        assert torch.equal(out, ref[:, 0]), case
+        assert bits_equal(out, ref[:, 0]), case
         rnd = (lambda a: None if a is None else a.astype(np.float32)) if f32 else (
             lambda a: None if a is None else a.astype(np.float16).astype(np.float32))
         want = c_oracle.pac_forward(rnd(x), rnd(gd), rnd(s), T)[:, 0]
@@ -318,7 +318,7 @@ def test_kxk_resident_launches_replay_from_a_hip_graph(c_oracle):
             got = acc.sum(0).cpu().numpy()
             acc0 = pkg.evaluation.new_accumulator(DEV)
             ref = m.forward_scored(xt, gt, None, tgt, acc0)                # eager resident launches in between
-            assert torch.equal(out, ref), k
+            assert bits_equal(out, ref), k
             assert np.allclose(got, acc0.sum(0).cpu().numpy(), rtol=1e-6)
         graphed.synchronize()
     F.ensure_resident_ok()
@@ -336,7 +336,7 @@ def test_odd_widths_stay_on_the_multi_launch_schedule(c_oracle):
         out2 = pkg.CSPN_ours.AffinityPropagate(T).forward_scored(dev(x), dev(gd), dev(s), dev(np.abs(x) + 0.1), acc)
     scale = float(np.abs(want).max())
     assert float(np.abs(out.cpu().numpy() - want).max()) <= 1e-5 * scale
-    assert torch.equal(out, out2)
+    assert bits_equal(out, out2)
 
 
 @pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 228, 304, 24), (2, 37, 40, 7), (1, 352, 1216, 24), (5, 60, 64, 9)],
@@ -355,7 +355,7 @@ def test_k3_fp32_training_forward_publishes_what_the_backward_needs(B, H, W, T, 
         wk0, _ = F.pac_prepare(gt)
         _, hist0 = F.propagate(wk0, xt, st, K, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True)
         out1, hist1, wk1 = F.pac_forward_resident_history(gt, xt, st, T)
-    assert torch.equal(wk1, wk0) and torch.equal(hist1, hist0) and torch.equal(out1, hist0[T - 1])
+    assert bits_equal(wk1, wk0) and bits_equal(hist1, hist0) and bits_equal(out1, hist0[T - 1])
     if B * H * W > 3 * 228 * 304:
         return
     cot = c_oracle.hash_normal(91, 9, (B, 1, H, W))
@@ -397,7 +397,7 @@ def test_dot2_form_against_the_oracle(B, H, W, T, S, sparse, c_oracle):
         fma = F.pac_forward_resident(gt, xt[:, 0].contiguous(), sp, T, steps_per_phase=S, step_form=F.STEP_FMA)
         again = F.pac_forward_resident(gt, xt[:, 0].contiguous(), sp, T, steps_per_phase=S, step_form=F.STEP_DOT2)
     F.ensure_resident_ok()
-    assert out.dtype == torch.float16 and torch.equal(out, again)
+    assert out.dtype == torch.float16 and bits_equal(out, again)
     f32 = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)      # noqa: E731
     want = c_oracle.pac_forward(f32(x), f32(gd), f32(s), T)[:, 0]
     scale = float(np.abs(want).max())
@@ -425,7 +425,7 @@ def test_dot2_form_scores_what_it_stores(c_oracle):
         ref = F.pac_forward_resident(gt, xt[:, 0].contiguous(), st[:, 0].contiguous(), T, step_form=F.STEP_DOT2)
         sums, _ = ev.all_gather_metric_sums(acc)
         want = ev.metric_sums(ref.unsqueeze(1), tt)
-    assert torch.equal(out, ref)
+    assert bits_equal(out, ref)
     assert np.allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
 
 
@@ -450,7 +450,7 @@ def test_k5_fp16_training_forward_on_the_dot2_kernel(B, H, W, T, sparse, c_oracl
                                plan=F.dtype_default_plan(K, wk0.dtype, None))
         out1, hist1, wk1 = F.pac_forward_resident_history(gt, xt, st, T)
     F.ensure_resident_ok()
-    assert hist1.dtype == torch.float16 and wk1.shape == wk0.shape and torch.equal(out1, hist1[T - 1])
+    assert hist1.dtype == torch.float16 and wk1.shape == wk0.shape and bits_equal(out1, hist1[T - 1])
     dw = (wk1.float() - wk0.float()).abs()
     assert float(dw.max()) <= 1.0 / 1024 and float((dw > 0).float().mean()) <= 0.01          # weights are <= 1: an ulp is <= 2^-11
     scale = float(hist0.float().abs().max())
@@ -500,7 +500,7 @@ def test_k5_resident_reverse_sweep_equals_the_streaming_one(B, H, W, T, sparse, 
             g16, out16 = F._reverse_sweep(wk, K, T, sp, cot.half(), None)
     F.ensure_resident_ok()
     assert g32 is cot or g32.data_ptr() == cot.data_ptr()
-    assert torch.equal(direct, out)
-    assert torch.equal(out, ref), float((out - ref).abs().max())
-    assert g16.dtype == torch.float32 and torch.equal(g16, cot.half().float())
-    assert torch.equal(out16, ref16), float((out16 - ref16).abs().max())
+    assert bits_equal(direct, out)
+    assert bits_equal(out, ref), float((out - ref).abs().max())
+    assert g16.dtype == torch.float32 and bits_equal(g16, cot.half().float())
+    assert bits_equal(out16, ref16), float((out16 - ref16).abs().max())

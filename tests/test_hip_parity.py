@@ -32,7 +32,7 @@ def run3(g, d, s, T, plan=None):
 
 
 def test_native_library_is_loaded():
-    assert _lib.lib().cspn_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib().cspn_abi_version() == _lib.ABI_VERSION == 10
     maps = open("/proc/self/maps").read()
     assert "libcspn_hip.so" in maps
 

@@ -9,7 +9,7 @@ import torch
 
 import cspn_monodepth_amd as pkg
 from cspn_monodepth_amd import functional as F
-from conftest import golden_names, load_golden, rel_err, rmse
+from conftest import bits_equal, lds_poison, golden_names, load_golden, rel_err, rmse
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -58,10 +58,35 @@ SHAPES = [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (8, 352, 12
 def test_resident_equals_multi_launch_bit_for_bit(B, H, W, T, sparse, c_oracle):
     g, d, s = c_oracle.synthetic_inputs(70 + B + T, B, H, W, 12, max(2, H * W // 140) if sparse else None)
     out, ref = both(g, d, s, T)
-    assert torch.equal(out, ref)
+    assert bits_equal(out, ref, T=T, sparse=sparse)
     if B * H * W <= 24 * 228 * 304:
         want = c_oracle.cspn3_forward(g, d, s, T)
         assert rel_err(out.cpu().numpy(), want) <= 1e-5 and rmse(out.cpu().numpy(), want) <= 1e-4
+
+
+# Shapes whose resident tiling leaves the last strip of a thread column partly PAST the region (wr % NQ != 0): those rows are
+# computed with zero taps and serve as the lower neighbour of the region's last row.  KITTI B = 8 is the production one.
+# (B, H, W, T): NQ, wr on 256 CUs — 8x352x1216: 5, 58; 4x228x304: 2, 51; 12x228x304: 3, 47; 16x228x304: 4, 79; 20x240x320: 5, 54;
+# 6x256x512x12: 4, 51; 2x300x400: 2, 47; then the shapes of configs 2 / 4 / 5 (wr % NQ == 0) and a single-phase one.
+STALE_LDS_SHAPES = [(8, 352, 1216, 24), (4, 228, 304, 24), (12, 228, 304, 24), (16, 228, 304, 24), (20, 240, 320, 24), (6, 256, 512, 12),
+                    (2, 300, 400, 24), (24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (5, 60, 64, 7)]
+
+
+@pytest.mark.parametrize("B,H,W,T", STALE_LDS_SHAPES, ids=["x".join(map(str, s)) for s in STALE_LDS_SHAPES])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_resident_result_does_not_depend_on_stale_lds(B, H, W, T, sparse, c_oracle):
+    """Round 5, the root cause of round 4's one-off mismatch of [sparse-8x352x1216x24]: LDS is not cleared between kernels, and
+    the blended CLEAN instances of cspn3_resident added a never-written private slot (m * d0) to the rows past the region; for a
+    bottom-edge tile that sum is the zero padding below the image, and a NaN / Inf bit pattern left there by an earlier kernel
+    (0 x NaN) spread into the last 24 rows of every image.  Only shapes with wr % NQ != 0 were exposed — KITTI B = 8 (config 4 on
+    one GPU) is the one among the tested shapes.  With a NaN fill of the whole LDS in front of EVERY launch (resident and
+    multi-launch alike) the results must still be the bits of the unpoisoned multi-launch schedule."""
+    g, d, s = c_oracle.synthetic_inputs(170 + B + T, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    _, ref = both(g, d, s, T)
+    with lds_poison():
+        out, ref_p = both(g, d, s, T)
+    assert bits_equal(ref_p, ref, T=T, sparse=sparse, which="multi-launch under poison")
+    assert bits_equal(out, ref, T=T, sparse=sparse, which="resident under poison")
 
 
 @pytest.mark.parametrize("name", golden_names("g1_") + golden_names("g2_") + ["g8_unet_hook"])
@@ -102,12 +127,12 @@ def test_resident_scored_and_phase_lengths(c_oracle):
             with resident("on"):
                 acc1 = ev.new_accumulator(DEV)
                 out = m.forward_scored(gt, dt, sp, tt, acc1)
-        assert torch.equal(out, ref)
+        assert bits_equal(out, ref)
         assert np.allclose(acc1.sum(0).cpu().numpy(), acc0.sum(0).cpu().numpy(), rtol=1e-6)
         for S in (4, 6, 8):
             with torch.no_grad():
                 o = F.forward_resident(gt, dt[:, 0], None if sp is None else sp[:, 0], T, int(sp is not None), steps_per_phase=S)
-            assert torch.equal(o, ref[:, 0]), S
+            assert bits_equal(o, ref[:, 0]), S
     F.check_resident_errors()
 
 
@@ -139,7 +164,7 @@ def test_resident_launches_from_several_streams_are_serialised(c_oracle):
     torch.cuda.synchronize()
     F.check_resident_errors()
     for a, b_ in zip(res, serial):
-        assert torch.equal(a, b_)
+        assert bits_equal(a, b_)
 
 
 def test_resident_timeout_is_repaired_not_a_hang(c_oracle):
@@ -157,7 +182,7 @@ def test_resident_timeout_is_repaired_not_a_hang(c_oracle):
         out = F.forward_resident(gt, dt, None, T, 0)                   # finds the error word, repairs `broken`, then runs
         torch.cuda.synchronize()
     assert F.resident_fallbacks() == 1
-    assert torch.equal(broken, ref[:, 0]) and torch.equal(out, ref[:, 0])
+    assert bits_equal(broken, ref[:, 0]) and bits_equal(out, ref[:, 0])
     F.ensure_resident_ok()
 
 
@@ -191,7 +216,7 @@ def test_resident_does_not_depend_on_leftover_state(c_oracle):
                 for rep in range(4):
                     m(*poison)
                     for k in (2, 0, 1, 1, 2, 0):
-                        assert torch.equal(m(*sets[k]), refs[k]), (B, H, W, rep, k)
+                        assert bits_equal(m(*sets[k]), refs[k]), (B, H, W, rep, k)
     F.check_resident_errors()
 
 
@@ -218,7 +243,7 @@ def test_resident_launch_replays_from_a_hip_graph(B, H, W, c_oracle):
             got = acc.sum(0).cpu().numpy()
             acc0 = pkg.evaluation.new_accumulator(DEV)
             ref = m.forward_scored(gt, dt, st, tgt, acc0)                      # eager resident launch in between
-            assert torch.equal(out, ref), k
+            assert bits_equal(out, ref), k
             assert np.allclose(got, acc0.sum(0).cpu().numpy(), rtol=1e-6)
         torch.cuda.synchronize()
     want = c_oracle.cspn3_forward(*ins[1], T)
@@ -240,7 +265,7 @@ def test_resident_training_forward_publishes_what_the_backward_needs(B, H, W, T,
     with torch.no_grad():
         _, hist0, w0, S0 = F.propagate_from_guidance(gt, dt, st, T, blend, keep_history=True, return_weights=True)
         out1, hist1, w1, S1 = F.forward_resident(gt, dt, st, T, int(sparse), keep_history=True)
-    assert torch.equal(hist1, hist0) and torch.equal(w1, w0) and torch.equal(S1, S0) and torch.equal(out1, hist0[T - 1])
+    assert bits_equal(hist1, hist0) and bits_equal(w1, w0) and bits_equal(S1, S0) and bits_equal(out1, hist0[T - 1])
     # through autograd (mode "on": the training forward takes the resident launch)
     cot = c_oracle.hash_normal(151, 9, (B, 1, H, W))
     wg, wd = c_oracle.cspn3_backward(g, d, s, cot, T, np.float64)
@@ -270,7 +295,7 @@ def test_resident_reverse_sweep_equals_multi_launch(B, H, W, T, sparse, c_oracle
     with resident("on"):
         _, out = F._reverse_sweep(w8, 3, T, sp, cot, None)
         direct = F.transposed_resident(w8, cot, sp, T)
-    assert torch.equal(out, ref) and torch.equal(direct, ref)
+    assert bits_equal(out, ref) and bits_equal(direct, ref)
     F.check_resident_errors()
 
 
@@ -293,16 +318,16 @@ def test_volume_free_reverse_sweep_equals_the_sweep_on_the_published_volume(B, H
     with resident("on"):
         direct = F.transposed_resident_guidance(gd, S, cot, sp, T)
         _, via = F._reverse_sweep(None, 3, T, sp, cot, None, guidance_S=(gd, S))
-        assert torch.equal(direct, ref) and torch.equal(via, ref)
+        assert bits_equal(direct, ref) and bits_equal(via, ref)
         if F.resident_supported(gd, d0, sp, T) is not None:
             blend = F.BLEND_SPARSE if sparse else F.BLEND_NONE
             o1, h1, w1, S1 = F.forward_resident(gd, d0, sp, T, blend, keep_history=True)
             o2, h2, w2, S2 = F.forward_resident(gd, d0, sp, T, blend, keep_history=True, publish_weights=False)
-            assert w2 is None and torch.equal(h1, h2) and torch.equal(S1, S2) and torch.equal(w1, w8) and torch.equal(S1, S)
-            assert torch.equal(F.transposed_resident_guidance(gd, S2, cot, sp, T), ref)
+            assert w2 is None and bits_equal(h1, h2) and bits_equal(S1, S2) and bits_equal(w1, w8) and bits_equal(S1, S)
+            assert bits_equal(F.transposed_resident_guidance(gd, S2, cot, sp, T), ref)
     with resident("off"):          # no resident sweep: the volume is rebuilt by cspn3_prepare, the streaming launches run on it
         _, off = F._reverse_sweep(None, 3, T, sp, cot, None, guidance_S=(gd, S))
-    assert torch.equal(off, ref)
+    assert bits_equal(off, ref)
     F.check_resident_errors()
 
 
@@ -321,7 +346,7 @@ def test_training_step_without_the_tap_volume_equals_the_one_with_it(c_oracle, m
             out.backward(cot)
             res.append((out.detach(), gt.grad, dt.grad))
         for a, b in zip(*res):
-            assert torch.equal(a, b)
+            assert bits_equal(a, b)
     F.check_resident_errors()
 
 
@@ -366,7 +391,7 @@ def test_timeout_in_the_last_scored_forward_is_repaired_where_the_sums_are_used(
             out = m.forward_scored(gt, dt, None, tg, acc)              # the last batch: nothing is launched after it
         total, _ = ev.all_gather_metric_sums(acc)                       # waits, repairs, THEN sums
         assert F.resident_fallbacks() == 1
-        assert torch.equal(out, ref)                                    # repaired in place: the same bits
+        assert bits_equal(out, ref)                                    # repaired in place: the same bits
         assert np.allclose(total.cpu().numpy(), want.cpu().numpy(), rtol=1e-7)
         assert ev.finalize_metrics(total)["count"] == 4 * 24 * 228 * 304
         # ... and finalize_metrics on the device accumulator is a consumer of its own
@@ -396,7 +421,7 @@ def test_three_timeouts_switch_auto_off_with_one_warning(c_oracle):
             assert F._RESIDENT_MODE == "off" and F.resident_fallbacks() == F._FALLBACK_LIMIT
             assert len([w for w in caught if issubclass(w.category, RuntimeWarning)]) == 1
         assert F.resident_supported(gt, dt[:, 0], None, 24) is None     # the next call takes the multi-launch schedule
-        assert all(torch.equal(o, ref) for o in outs) and torch.equal(m(gt, dt), ref)
+        assert all(bits_equal(o, ref) for o in outs) and bits_equal(m(gt, dt), ref)
 
 
 def test_contended_device_results_equal_uncontended(c_oracle):
@@ -463,7 +488,7 @@ def test_contended_device_results_equal_uncontended(c_oracle):
                 break
         assert F.resident_fallbacks() >= 1                               # launches did give up, and were repaired
     for a, b_ in zip(outs, ref_outs):
-        assert torch.equal(a, b_)
+        assert bits_equal(a, b_)
     # (the repaired batches are scored by the separate reduction — another summation order — and the failed launches' partial
     # sums are subtracted in fp64: equal to ~1e-9, not to the bit)
     assert np.allclose(total.cpu().numpy(), ref_total.cpu().numpy(), rtol=1e-7)
@@ -514,7 +539,7 @@ def test_many_phases_repeated_on_one_workspace(c_oracle):
             assert F.resident_supported(sets[0][0], sets[0][1][:, 0], None, T) is not None
             for rep in range(12):
                 for k in (0, 1, 1, 0):
-                    assert torch.equal(m(*sets[k]), refs[k]), (rep, k)
+                    assert bits_equal(m(*sets[k]), refs[k]), (rep, k)
     F.ensure_resident_ok()
     assert F._RES_SEQ_STEP >= 256
     with pytest.raises(RuntimeError, match="255 phases"):
@@ -540,7 +565,7 @@ def test_random_shapes_resident_equals_multi_launch(seed, c_oracle):
                 ref = m(dev(g), dev(d), dev(s))
             out = F.forward_resident(dev(g), dev(d)[:, 0].contiguous(), None if s is None else dev(s)[:, 0].contiguous(), T, int(sparse),
                                      steps_per_phase=S)
-        assert torch.equal(out, ref[:, 0]), (B, H, W, T, S, sparse)
+        assert bits_equal(out, ref[:, 0]), (B, H, W, T, S, sparse)
         want = c_oracle.cspn3_forward(g, d, s, T)
         assert rel_err(out.cpu().numpy(), want[:, 0]) <= 1e-5, (B, H, W, T, S, sparse)
         done += 1
