@@ -17,6 +17,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def _run(cmd):
     env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("CSPN_DEBUG_LDS_POISON", None)      # a poisoned-LDS run of the suite (every launch preceded by an LDS fill) must not reach the timed bench
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -30,13 +30,31 @@ def grad_close(got, want, tol):
     return float(np.abs(got - want).max()) <= tol * max(1.0, float(np.abs(want).max()))
 
 
-# (label, B, H, W, expected threads of the forward instance, expected steps per launch)
+# (label, B, H, W, expected threads of the multi-launch forward instance, expected steps per launch)
 CASES3 = [
     ("config2_nyu_b24", 24, 228, 304, 1024, 8),
     ("config5_shard_nyu_b3", 3, 228, 304, 512, 8),
     ("config4_shard_kitti_b1", 1, 352, 1216, 1024, 8),
     ("config4_kitti_b8", 8, 352, 1216, 1024, 8),
 ]
+# The instance the DEFAULT path really runs: under no-grad the module takes cspn3_resident (MODE 0 / 1), under
+# grad its training forms (MODE 2 forward with history, MODE 4 reverse sweep) — all on the tiling cspn3_resident_plan finds for the
+# shape on the device's CUs.  label -> (steps per phase, tiles_x, tiles_y, tile_w, tile_h, quads per thread = the NQ template
+# argument, images per launch, launches) on the 256 CUs of an MI355X; a change to resident_geometry (cspn_resident.hip) that moves
+# a production shape to another instance must show up here.
+RESIDENT3 = {
+    "config2_nyu_b24": (8, 2, 5, 152, 46, 5, 24, 1),
+    "config5_shard_nyu_b3": (8, 7, 12, 44, 19, 1, 3, 1),
+    "config4_shard_kitti_b1": (8, 11, 22, 112, 16, 2, 1, 1),
+    "config4_kitti_b8": (8, 8, 8, 152, 44, 5, 4, 2),
+}
+_RP_KEYS = ("steps_per_phase", "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread", "images_per_launch", "launches")
+
+
+def assert_resident_instance(rp, want, label):
+    assert torch.cuda.get_device_properties(0).multi_processor_count == 256, "the expected tilings are those of an MI355X (256 CUs)"
+    assert rp is not None, label
+    assert tuple(rp[k] for k in _RP_KEYS) == want and rp["threads"] in (512, 768, 256, 1024), (label, {k: rp[k] for k in _RP_KEYS})
 
 
 @pytest.mark.parametrize("label,B,H,W,threads,S", CASES3, ids=[c[0] for c in CASES3])
@@ -55,6 +73,12 @@ def test_cspn3_forward_backward_production(label, B, H, W, threads, S, sparse, c
     m = pkg.CSPN_new.AffinityPropagate(T, 3)
     gt, dt, st = dev(g, True), dev(d, True), dev(s)
     assert F.from_guidance_supported(gt, dt[:, 0], None if st is None else st[:, 0])   # the fused-prepare entry runs
+    # ... and the weight-resident launches serve both the no-grad call and the training forms, on this tiling
+    assert F._RESIDENT_MODE == "auto"
+    rp = F.resident_supported(gt.detach(), dt.detach()[:, 0], None if st is None else st[:, 0], T)
+    assert_resident_instance(rp, RESIDENT3[label], label)
+    assert rp["threads"] == 512
+    n_res = F._resident_state(gt.device)["seq"]
     out = m(gt, dt, st)
     out.backward(dev(cot))
     torch.cuda.synchronize()
@@ -65,7 +89,9 @@ def test_cspn3_forward_backward_production(label, B, H, W, threads, S, sparse, c
     assert torch.count_nonzero(gt.grad[:, 8:]) == 0
     with torch.no_grad():                                              # the no-grad entry (what bench.py's step runs)
         o2 = m(gt.detach(), dt.detach(), st)
-    assert bits_equal(o2, out.detach())
+    assert bits_equal(o2, out.detach(), T=T, sparse=sparse)
+    # three resident calls were issued: training forward (MODE 2), reverse sweep (MODE 4), no-grad forward (MODE 0)
+    assert F._resident_state(gt.device)["seq"] - n_res == 3 * F._RES_SEQ_STEP and F.resident_fallbacks() == 0
 
 
 def _pac_inputs(c_oracle, B, H, W, K, sparse):
@@ -86,6 +112,12 @@ def test_config3_full_size_fp16(sparse, c_oracle):
     x, gd, s = _pac_inputs(c_oracle, B, H, W, K, sparse)
     x16, gd16 = x.astype(np.float16), gd.astype(np.float16)
     s16 = None if s is None else s.astype(np.float16)
+    # the instance the default (no-grad) call really runs: cspnk_d2<BLEND, MODE, CLEAN, 768> — ONE launch of 2 x 12 images on a
+    # 2 x 10 tiling with 4-step phases, the dot-product step form (fp16 planes: state_dtype None); fp32 planes ("reference")
+    # stay on the FMA kernel cspnk_resident with the same tiling, two launches
+    kp = F.pac_resident_supported(dev(gd16), dev(x16)[:, 0], None if s16 is None else dev(s16)[:, 0], T)
+    assert_resident_instance(kp, (4, 2, 10, 152, 23, 1, 12, 2), "config3")
+    assert kp["threads"] == 768 and F._KRES_STEP_FORM == F._lib.STEP_AUTO
     f32 = lambda a: None if a is None else a.astype(np.float32)       # noqa: E731
     want = c_oracle.pac_forward(f32(x16), f32(gd16), f32(s16), T)
     scale = float(np.abs(want).max())
