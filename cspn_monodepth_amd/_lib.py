@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("CSPN_HIP_LIB") or os.path.join(_PKG, "libcspn_hip.so")   # env override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
-SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "cspn_debug.hip", "pac_conv2d.hip", "pac_conv2d_s2.hip", "cspn_unpool.hip")   # one TU each
+SOURCES = ("cspn_propagate.hip", "cspn_resident.hip", "cspnk_resident.hip", "cspnk_d2.hip", "cspn_prepare.hip", "cspn_backward.hip", "cspn_metrics.hip", "cspn_debug.hip", "cspn_repair.hip", "pac_conv2d.hip", "pac_conv2d_s2.hip", "cspn_unpool.hip")   # one TU each
 HEADERS = (os.path.join(CSRC, "cspn_common.hpp"), os.path.join(CSRC, "cspnk_helpers.hpp"), os.path.join(_ROOT, "include", "cspn_hip.h"))
 INCLUDE = os.path.join(_ROOT, "include")
 
@@ -44,7 +44,7 @@ class cspn_resident_plan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("steps_per_phase", "tiles_x", "tiles_y", "tile_w", "tile_h", "quads_per_thread",
                                             "threads", "images_per_launch", "launches", "lds_bytes", "n_cu")] + \
                [("region_over_tile", ctypes.c_float), ("spin_limit", ctypes.c_uint), ("debug_stamps", ctypes.c_void_p),
-                ("step_form", ctypes.c_int)]
+                ("step_form", ctypes.c_int), ("guard", ctypes.c_int)]
 
 
 STEP_AUTO, STEP_FMA, STEP_DOT2 = 0, 1, 2       # cspn_resident_plan.step_form (include/cspn_hip.h)

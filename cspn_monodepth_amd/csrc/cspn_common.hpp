@@ -34,6 +34,11 @@ bool pac_s2_geometry(int kh, int kw, int sh, int sw, int ph, int pw, int dh, int
 int pac_s2_forward(const void* in, const void* kern, void* out, int dtype, int K, const PacS2Args& a, void* stream);
 int pac_s2_grad_input(const void* gout, const void* kern, void* gin, int dtype, int K, const PacS2Args& a, void* stream);
 int pac_s2_grad_kernel(const void* gout, const void* in, void* gk, int dtype, int K, const PacS2Args& a, void* stream);
+// cspn_repair.hip: the guard behind a plain resident inference launch (cspn_resident_plan.guard): re-computes the call's result
+// on the stream when — and only when — its launches gave up (abort word == seq)
+bool resident_repair_fits(int T);
+int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, const unsigned* abort_word,
+                           unsigned seq, int B, int H, int W, int Wv, int T, int blend, int n_cu, void* stream);
 // cspn_debug.hip: the poisoned-LDS debugging aid (include/cspn_hip.h: cspn_debug_set_lds_poison)
 extern int g_lds_poison_on;
 void lds_poison(hipStream_t st);

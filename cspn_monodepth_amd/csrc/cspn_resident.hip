@@ -760,7 +760,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 // d_T in the training forward, G_0 in the reverse sweep) becomes NaN, so that a result consumed before the
                 // host has looked at the error word is visibly wrong instead of stale allocator memory.
                 {
-                    const float qnan = __uint_as_float(0x7fc00000u);
+                    const float qnan = __uint_as_float(CSPN_POISON_F32);      // NaN with the payload the host looks for
                     float* const pz = HIST ? uniform_ptr(a.hist + (size_t)(a.T - 1) * plane + (size_t)b * HW) : dout;
                     unsigned o0 = (unsigned)(yq0L * W + xqL);
                     asm volatile("" : "+v"(o0));
@@ -1107,6 +1107,9 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);   // x (sc1 load + s_sleep) ~ seconds
     a.dbg = rp.debug_stamps;
     const bool clean = regions_inside_image(g, H, W, a.Wv, T);
+    // (refused rather than ignored: a host that asked for the guard relies on `out` being complete for GPU-side consumers)
+    if (rp.guard && (mode != 0 || !out || !cspn_detail::resident_repair_fits(T)))
+        return fail("cspn3_forward_resident: plan->guard serves plain inference calls (no history, no scoring, CSPN_new weights) of T <= 54 steps");
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
@@ -1123,6 +1126,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         }
         if (!ok) return 0;
     }
+    if (rp.guard)
+        return cspn_detail::resident_repair_launch(a.g, bs, cs, a.d0, a.sparse, a.out, a.status, seq, B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st);
     return 1;
 }
 

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
                 __atomic_thread_fence(__ATOMIC_SEQ_CST);
             }
             // poison what this workgroup will never produce — this round's tile and the tiles of its remaining rounds — with NaN
-            const uint4 qn = make_uint4(0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u);
+            constexpr unsigned pz2 = CSPN_POISON_F16 | (CSPN_POISON_F16 << 16);      // NaN with the payload the host looks for
+            const uint4 qn = make_uint4(pz2, pz2, pz2, pz2);
             __half* const pz = HIST ? static_cast<__half*>(a.hist) + (size_t)(a.T - 1) * plane : static_cast<__half*>(a.out);   // x_T
             for (int r2 = round; r2 < a.rounds; ++r2) {
                 const int b2 = a.b0 + r2 * a.nb + bl;

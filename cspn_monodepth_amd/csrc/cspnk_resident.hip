@@ -544,10 +544,15 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                     __atomic_thread_fence(__ATOMIC_SEQ_CST);
                 }
                 // poison what this tile will never produce (NaN in the plane dtype), as cspn3_resident does
-                float qn[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qn[e] = __uint_as_float(0x7fc00000u);
-                const Oct o = IO::from_f8(qn);
+                // (bit patterns, not conversions: the payload is what the host recognises a failed tile by)
+                Oct o;
+                if constexpr (sizeof(ST) == 2) {
+                    constexpr unsigned pz2 = CSPN_POISON_F16 | (CSPN_POISON_F16 << 16);
+                    o.a = make_uint4(pz2, pz2, pz2, pz2);
+                } else {
+                    o.a = make_uint4(CSPN_POISON_F32, CSPN_POISON_F32, CSPN_POISON_F32, CSPN_POISON_F32);
+                    o.b = o.a;
+                }
                 ST* const pz = TRANS ? kuniform_ptr(static_cast<ST*>(a.hist) + (size_t)(a.T - 1) * plane + (size_t)b * HW) : outb;   // G_0 / the refined depth
 #pragma unroll
                 for (int i = 0; i < NO; ++i)

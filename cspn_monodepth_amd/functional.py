@@ -542,6 +542,18 @@ def resident_fallbacks():
 _RES_SEQ_STEP = 256
 _RES_SEQ_MAX = (1 << 31) - 4096
 _RESIDENT_SPIN_LIMIT = 0   # test hook: polls before a neighbour wait gives up (0 = the engine's default, ~seconds)
+# The guard (include/cspn_hip.h: cspn_resident_plan.guard): plain inference calls — whose result goes to a consumer this package
+# does not know (a loss, a .cpu(), an image writer) — carry a device-side repair behind the resident launch, so that a timed-out
+# launch is re-computed ON THE STREAM before anything can read it.  The scored calls (consumer = this package's metric gather,
+# which repairs on the host first) and the training forms do not.  Costs one empty launch (~2 us); CSPN_RESIDENT_GUARD=0 or
+# set_resident_guard(False) for A/B runs.
+_RESIDENT_GUARD = os.environ.get("CSPN_RESIDENT_GUARD", "1") != "0"
+_GUARD_MAX_T = 54
+
+
+def set_resident_guard(enabled):
+    global _RESIDENT_GUARD
+    _RESIDENT_GUARD = bool(enabled)
 
 
 def set_resident(mode):
@@ -578,25 +590,73 @@ def _resident_state(dev):
 
 
 def _note_fallback(training=False):
-    """Count a detected time-out; switch mode "auto" off after _FALLBACK_LIMIT of them (at once for a training-form launch: the
-    step that raised is about to be retried)."""
+    """Count a detected time-out and say so — every time, in every mode (a silent repair hides a mis-shared GPU) —
+    and switch mode "auto" off after _FALLBACK_LIMIT of them (at once for a training-form launch: the step that raised is about
+    to be retried)."""
     global _FALLBACKS, _RESIDENT_MODE, _FALLBACK_WARNED
+    import warnings
     _FALLBACKS += 1
     if _RESIDENT_MODE == "auto" and (training or _FALLBACKS >= _FALLBACK_LIMIT):
         _RESIDENT_MODE = "off"
         if not _FALLBACK_WARNED:
             _FALLBACK_WARNED = True
-            import warnings
             warnings.warn("cspn_monodepth_amd: %d weight-resident launch(es) timed out waiting for co-residency (the GPU is shared "
                           "with another tenant); the resident schedule is switched off for this process — results are unchanged, "
                           "calls take the multi-launch schedule from now on (functional.set_resident('auto') re-enables it)"
                           % _FALLBACKS, RuntimeWarning, stacklevel=3)
+            return
+    warnings.warn("cspn_monodepth_amd: weight-resident launch time-out #%d on this process (the GPU is shared with another tenant, so "
+                  "the launch's workgroups were not co-resident): the affected inference results are re-computed on the multi-launch "
+                  "schedule (same bits); until that repair their missing tiles read as NaN — see functional.set_resident('safe' / 'off')"
+                  % _FALLBACKS, RuntimeWarning, stacklevel=3)
+
+
+POISON_F32, POISON_F16 = 0x7fc0dead, 0x7ead      # include/cspn_hip.h: CSPN_POISON_F32 / CSPN_POISON_F16
+
+
+def _holds_poison(t):
+    """Does `t` hold the NaN pattern a tile that gave up writes (CSPN_POISON_*)?  Exact: no arithmetic produces that payload, so a
+    NaN the recurrence itself produced (0/0 at an all-zero gate pixel, as in the reference) is not mistaken for a failed tile."""
+    if t.dtype == torch.float32:
+        return bool((t.view(torch.int32) == POISON_F32).any())
+    return bool((t.view(torch.int16) == POISON_F16).any())
+
+
+def _poison_mask(t):
+    return (t.view(torch.int32) == POISON_F32) if t.dtype == torch.float32 else (t.view(torch.int16) == POISON_F16)
+
+
+def _nothing():
+    pass
+
+
+class _JournalEntry(object):
+    """One resident launch that may still turn out to have timed out.  redo: re-runs the call on the multi-launch schedule into
+    the same output tensor (None: a training-form launch / anything that cannot be repaired after the fact); out: the tensor a
+    failed tile poisons; inputs: the tensors the repair would read, with their version counters at launch time — a repair from
+    inputs the caller has since overwritten in place would silently produce the result of ANOTHER batch."""
+    __slots__ = ("redo", "out", "inputs", "versions", "nbytes", "what", "guarded")
+
+    def __init__(self, redo, out=None, inputs=(), what="resident launch", guarded=False):
+        # guarded: the launch carried its own device-side repair (cspn_resident_plan.guard) — nothing to redo, no tensor kept alive
+        self.guarded = guarded
+        if guarded:
+            redo, out, inputs = _nothing, None, ()
+        self.redo, self.out, self.what = redo, out, what
+        self.inputs = tuple(t for t in inputs if t is not None)
+        self.versions = tuple(t._version for t in self.inputs)
+        self.nbytes = sum(t.numel() * t.element_size() for t in self.inputs) + (0 if out is None else out.numel() * out.element_size())
+
+    def inputs_untouched(self):
+        return all(t._version == v for t, v in zip(self.inputs, self.versions))
 
 
 def _recover(dev, st):
-    """The error word of `dev` is set: wait for the journaled launches, clear the word, and re-run the journaled inference calls
-    on the multi-launch schedule into their own output tensors.  Raises ResidentLaunchTimeout when a launch that cannot be
-    repaired is among them (training form, graph replay, or a journal that overflowed since the last clean check)."""
+    """The error word of `dev` is set: wait for the journaled launches, clear the word, and re-run — on the multi-launch schedule,
+    into their own output tensors — exactly the journaled inference calls whose output holds the poison pattern of a tile that gave
+    up.  Calls that finished cleanly are left alone (their inputs may have been reused since).  Raises ResidentLaunchTimeout
+    when a launch that cannot be repaired is among the suspects: a training-form launch, a graph replay, a journal that overflowed
+    since the last clean check, or a failed call whose inputs were modified in place after the launch."""
     with st["lock"]:
         if st["host_err_np"][0] == 0:
             return
@@ -609,46 +669,70 @@ def _recover(dev, st):
         lost, st["lost"] = st["lost"], False
         st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
         st["marks"] = []
-        training = any(redo is None for redo in journal)
+        st["jbytes"] = st["jbytes_since_mark"] = 0
+        training = any(e.redo is None for e in journal)
         _note_fallback(training=training)
-        if lost or training or not journal:
+        stale = []
+        repaired = 0
+        with _device_guard(dev):
+            for e in journal:
+                if e.guarded:
+                    repaired += 1                  # (if it was this one, its guard kernel has re-computed it on the stream)
+                    continue
+                if e.redo is None or e.out is None or not _holds_poison(e.out):
+                    continue                       # finished cleanly (or cannot be looked at: handled below)
+                if not e.inputs_untouched():
+                    stale.append(e.what)
+                    continue
+                e.redo()
+                repaired += 1
+        if lost or training or stale or not repaired:
+            why = ("a training-form launch" if training else
+                   "the inputs of the failed call (%s) were modified in place before the time-out was detected" % ", ".join(stale) if stale
+                   else "graph replay / unchecked launches beyond the journal")
             raise ResidentLaunchTimeout(
                 "a weight-resident launch on cuda:%d timed out waiting for a neighbouring tile (the GPU was shared with another "
                 "long-running tenant, so the launch was not co-resident) and its result cannot be repaired in place (%s); the "
                 "output of that call is incomplete (its missing tiles are NaN).  The resident schedule is now off for this "
-                "process (functional.set_resident): re-run the step." % (
-                    dev.index, "a training-form launch" if training else "graph replay / unchecked launches beyond the journal"))
-        with _device_guard(dev):
-            for redo in journal:
-                redo()
+                "process (functional.set_resident): re-run the step." % (dev.index, why))
 
 
-def _journal_add(dev, st, redo, stream):
-    """Remember how to repair the launch just issued on `stream` (redo = None: it cannot be repaired).  The journal is bounded
-    without ever losing an entry that may still fail: every 16th launch records an event behind itself, and when the journal is
-    full the host waits for the oldest of those marks — 16+ launches back, normally long finished, so the wait returns at once —
-    and drops what lies before it (or repairs everything, if the error word is set by then)."""
+_JOURNAL_MARK_BYTES = 64 << 20      # a completion mark at least every 64 MB of journaled tensors (or every 16 launches)
+
+
+def _journal_add(dev, st, entry, stream):
+    """Remember how to repair the launch just issued on `stream`.  The journal never loses an entry that may still fail, and it
+    does not pin memory for long (32 unchecked config-2 batches were 2.5 GB): a completion mark (an event) is recorded
+    every 16 launches or 64 MB of journaled tensors, whichever comes first, every add drops what lies before the marks that have
+    completed (a poll, no wait), and a full journal waits for its oldest mark (normally long finished)."""
     j = st["journal"]
-    j.append(redo)
+    j.append(entry)
     st["jcount"] = n = st.get("jcount", 0) + 1
+    st["jbytes_since_mark"] = since = st.get("jbytes_since_mark", 0) + entry.nbytes
     marks = st.setdefault("marks", [])
-    if n % 16 == 0:
+    if n % 16 == 0 or since >= _JOURNAL_MARK_BYTES:
         pool = st.setdefault("mark_pool", [])
         ev = pool.pop() if pool else torch.cuda.Event()
         ev.record(stream)
         marks.append([len(j), ev])
-    if len(j) >= _JOURNAL_MAX:
-        if st["host_err_np"][0] == 0 and marks:
-            cut, ev = marks.pop(0)
-            ev.synchronize()
+        st["jbytes_since_mark"] = 0
+    if marks and st["host_err_np"][0] == 0:
+        cut = 0
+        while marks:
+            c, ev = marks[0]
+            if not ev.query():
+                if len(j) - cut < _JOURNAL_MAX:
+                    break
+                ev.synchronize()                   # a full journal waits for its oldest mark
+            marks.pop(0)
             st["mark_pool"].append(ev)
-            if st["host_err_np"][0] == 0:          # everything up to the mark has finished cleanly
-                del j[:cut]
-                for m in marks:
-                    m[0] -= cut
-                return
-        if st["host_err_np"][0] != 0:
-            _recover(dev, st)
+            cut = c
+        if cut and st["host_err_np"][0] == 0:      # everything up to the mark has finished cleanly
+            del j[:cut]
+            for m in marks:
+                m[0] -= cut
+    if st["host_err_np"][0] != 0:
+        _recover(dev, st)
 
 
 def _device_is_oversubscribed():
@@ -717,6 +801,7 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
 def _journal_clear(st):
     del st["journal"][:]
     st["lost"] = False
+    st["jbytes_since_mark"] = 0
     st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
     st["marks"] = []
 
@@ -813,7 +898,8 @@ class _ResidentCheckpoint(object):
         check_resident_errors(self.dev)
 
 
-def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None, reports_done=False, redo=None):
+def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_bytes_fn=None, reports_done=False, redo=None,
+                     out=None, inputs=(), what="resident launch", guarded=False):
     """The host protocol of every resident launch on `dev`: one at a time per device (the device's own lock; a launch from
     another stream first waits for the previous one's stream), a zero-initialised workspace per (B,H,W), a growing flag sequence
     number, the error word looked at before the call (a time-out of an earlier launch is repaired or raised there: _recover).
@@ -882,19 +968,28 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
                 st["last_reports"] = bool(reports_done)
                 if reports_done:                        # training-form launches store `seq` to the completion word
                     st["last_seq"] = seq
-                _journal_add(dev, st, redo, cur)
+                _journal_add(dev, st, _JournalEntry(redo, out, inputs, what, guarded), cur)
     return ok
 
 
-def _with_spin_limit(cp, step_form=0):
-    """The cached ctypes plan, or a copy carrying the test hook's spin limit / a pinned step form."""
-    if (not _RESIDENT_SPIN_LIMIT and not step_form) or cp is None:
+def _with_spin_limit(cp, step_form=0, guard=0):
+    """The cached ctypes plan, or a copy carrying the test hook's spin limit / a pinned step form / the guard flag."""
+    if (not _RESIDENT_SPIN_LIMIT and not step_form and not guard) or cp is None:
         return cp
+    if guard and not _RESIDENT_SPIN_LIMIT and not step_form:      # the common case: one guarded copy per cached plan
+        c2 = getattr(cp, "_guarded", None)
+        if c2 is None:
+            c2 = _lib.cspn_resident_plan()
+            ctypes.memmove(ctypes.byref(c2), ctypes.byref(cp), ctypes.sizeof(c2))
+            c2.guard = 1
+            cp._guarded = c2
+        return c2
     c2 = _lib.cspn_resident_plan()
     ctypes.memmove(ctypes.byref(c2), ctypes.byref(cp), ctypes.sizeof(c2))
     if _RESIDENT_SPIN_LIMIT:
         c2.spin_limit = int(_RESIDENT_SPIN_LIMIT)
     c2.step_form = int(step_form)
+    c2.guard = int(guard)
     return c2
 
 
@@ -903,7 +998,7 @@ def _unscore_failed_launch(out, tg, acc):
     return before their scoring; their part of `out` is NaN).  Take those sums out again, so that the re-run can score the whole
     batch exactly once: they are the metric sums over the finite part of the failed output."""
     from . import evaluation
-    bad = torch.isnan(out)
+    bad = _poison_mask(out)
     part = evaluation.metric_sums(torch.where(bad, torch.ones_like(out), out), torch.where(bad, torch.zeros_like(tg), tg))
     acc[0] -= part
 
@@ -973,7 +1068,7 @@ def pac_transposed_resident(wk, g_T, sparse, T):
 
 
 def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None,
-                     keep_history=False, publish_weights=True):
+                     keep_history=False, publish_weights=True, guard=None):
     """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it.
 
     keep_history=True is the training forward: returns (d_T [view of history[T-1]], history [T,B,H,W], w8 [B,8,H,W],
@@ -993,14 +1088,16 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     tg, acc = score if score is not None else (None, None)
     rp = None
+    guard = int(_RESIDENT_GUARD and score is None and not keep_history and int(T) <= _GUARD_MAX_T) if guard is None else int(guard)
     if steps_per_phase or spin_limit or debug_stamps is not None:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
+        rp.guard = guard
     else:
         # found once per shape: the C side skips its search
-        rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(blend), dev)[1])
+        rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(blend), dev)[1], guard=guard)
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspn3_forward_resident(_p(guidance), guidance.stride(0), guidance.stride(1), _p(d0), _p(sparse), _p(out),
                                         _p(hist), _p(w8), _p(S_out), _p(work), seq, host_err_ptr, B, H, W, int(valid_w),
@@ -1020,7 +1117,8 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
             if score is not None:
                 evaluation.metric_sums(out, tgp, out=acc)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo, out=out,
+                          inputs=(guidance, d0, sparse, tg), what="cspn3_forward_resident %dx%dx%d" % (B, H, W), guarded=bool(guard))
     _lib.check(ok, "cspn3_forward_resident")
     if keep_history:
         return hist[int(T) - 1], hist, w8, S_out
@@ -1136,7 +1234,8 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
             evaluation.metric_sums(out, tg, out=acc)
 
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
-                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), redo=redo)
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), redo=redo, out=out,
+                          inputs=(guided, x0, sparse, tg), what="cspnk_forward_resident %dx%dx%d" % (B, H, W))
     _lib.check(ok, "cspnk_forward_resident")
     return out
 

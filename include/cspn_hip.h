@@ -58,6 +58,12 @@ extern "C" {
 
 #define CSPN_ABI_VERSION 10
 
+/* What a tile of a weight-resident launch that gave up (co-residency time-out) leaves in its part of the result: a quiet NaN with
+ * a payload no arithmetic produces.  A consumer sees NaN; the host tells a failed tile from a NaN the recurrence itself produced
+ * (0/0 at an all-zero gate pixel, CSPN_new.py:127) by the bit pattern, and re-runs exactly the calls that hold one. */
+#define CSPN_POISON_F32 0x7fc0deadu
+#define CSPN_POISON_F16 0x7eadu
+
 typedef void* cspn_stream_t; /* hipStream_t */
 
 /* element types */
@@ -274,6 +280,13 @@ typedef struct cspn_resident_plan {
     unsigned long long* debug_stamps; /* in: developer probe, device buffer [workgroups][16] of 100 MHz wall-clock stamps
                                        * (start, weights derived, then per phase: staged, steps done, exchanged) or NULL */
     int step_form;          /* cspnk_forward_resident, in: CSPN_STEP_AUTO (0), CSPN_STEP_FMA or CSPN_STEP_DOT2 — see there */
+    int guard;              /* cspn3_forward_resident, in (ABI 10): != 0 enqueues a guard kernel behind the call's launch(es).  It reads
+                             * the call's abort word and returns at once unless a tile gave up (co-residency time-out); then it
+                             * re-computes the whole refined depth on the stream, with the resident kernel's arithmetic (bit-identical).
+                             * Whatever consumes `out` later on that stream — any GPU kernel, a copy to the host — sees the finished
+                             * tensor, as with the reference's ATen module (CSPN_new.py:80-92); the error words are still set, for the
+                             * host's statistics.  Plain inference calls only (no history, no scoring), T <= 54; refused otherwise.
+                             * Costs the success path one empty launch (~2 us on the stream). */
 } cspn_resident_plan;
 #define CSPN_STEP_AUTO 0   /* the dot-product form where it exists (K = 5, fp16 guidance, fp16 planes), else the FMA form  */
 #define CSPN_STEP_FMA 1    /* one v_fma_mix_f32 per tap, fp32 state inside a phase: the bits of the multi-launch schedule   */
