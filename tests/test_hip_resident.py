@@ -169,16 +169,17 @@ def test_resident_launches_from_several_streams_are_serialised(c_oracle):
 
 def test_resident_timeout_is_repaired_not_a_hang(c_oracle):
     """A neighbour wait that gives up (spin limit forced to 1 poll) must end the launch; the next launch on the device finds the
-    error word and re-runs the failed call on the multi-launch schedule INTO THE SAME TENSOR — no raise, the same bits."""
+    error word and re-runs the failed call on the multi-launch schedule INTO THE SAME TENSOR — no raise, the same bits.  (The HOST
+    repair: the call is made without the device-side guard, as scored calls are.)"""
     B, H, W, T = 24, 228, 304, 24
     g, d, _ = c_oracle.synthetic_inputs(99, B, H, W, 12, None)
     gt, dt = dev(g), dev(d)[:, 0].contiguous()
     with torch.no_grad():
         with resident("off"):
             ref = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dev(d))
-        broken = F.forward_resident(gt, dt, None, T, 0, spin_limit=1)
+        broken = F.forward_resident(gt, dt, None, T, 0, spin_limit=1, guard=0)
         torch.cuda.synchronize()
-        assert bool(torch.isnan(broken).any()) and F.resident_fallbacks() == 0     # poisoned, and nobody has looked yet
+        assert bool(torch.isnan(broken).any()) and F._holds_poison(broken) and F.resident_fallbacks() == 0     # poisoned, and nobody has looked yet
         out = F.forward_resident(gt, dt, None, T, 0)                   # finds the error word, repairs `broken`, then runs
         torch.cuda.synchronize()
     assert F.resident_fallbacks() == 1

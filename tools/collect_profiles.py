@@ -59,7 +59,7 @@ if os.path.exists(f):
         m = re.match(r"T=(\d+) S=(\d+) plan (\{.*\}); call \(events\) ([\d.]+) us", line)
         if m:
             cur = {"plan": eval(m.group(3)), "call_us_with_stamps": float(m.group(4)), "phases": []}   # noqa: S307
-            tl["cspnk_resident_pac5_T%s_S%s" % (m.group(1), m.group(2))] = cur
+            tl["cspnk_d2_pac5_T%s_S%s" % (m.group(1), m.group(2))] = cur
         m = re.match(r"\s+(\w+)\s+mean ([\d.]+)\s+min ([\d.]+)\s+max ([\d.]+)\s+\(ends ([\d.]+) \.\. ([\d.]+) us", line)
         if m and cur is not None:
             cur["phases"].append({"phase": m.group(1), "mean_us": float(m.group(2)), "min_us": float(m.group(3)),
