@@ -37,8 +37,9 @@ int pac_s2_grad_kernel(const void* gout, const void* in, void* gk, int dtype, in
 // cspn_repair.hip: the guard behind a plain resident inference launch (cspn_resident_plan.guard): re-computes the call's result
 // on the stream when — and only when — its launches gave up (abort word == seq)
 bool resident_repair_fits(int T);
-int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, const unsigned* abort_word,
-                           unsigned seq, int B, int H, int W, int Wv, int T, int blend, int n_cu, void* stream);
+int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, float* hist, float* s_out,
+                           float* w_out, const float* s_in, int mode, const unsigned* abort_word, unsigned seq, int B, int H, int W, int Wv,
+                           int T, int blend, int n_cu, void* stream);      // mode 0: inference, 2: training forward, 4: volume-free reverse sweep
 // cspn_debug.hip: the poisoned-LDS debugging aid (include/cspn_hip.h: cspn_debug_set_lds_poison)
 extern int g_lds_poison_on;
 void lds_poison(hipStream_t st);

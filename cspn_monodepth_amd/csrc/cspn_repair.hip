@@ -24,77 +24,139 @@ constexpr int REP_TILE = 32, REP_THREADS = 256;
 struct RepArgs {
     const float* g; long g_bs, g_cs;
     const float* d0; const float* sparse; float* out;
+    float* hist; float* s_out; float* w_out; const float* s_in;
     const unsigned* abort_word; unsigned seq;
     int B, H, W, Wv, T, tiles_x, tiles_y;
 };
 
-template <int BLEND>
+// the forward's refined reciprocal of the normaliser (div8_shared_reciprocal's recipe), as cspn3_resident MODE 4 forms it
+__device__ __forceinline__ float rcp_as_forward(float S) {
+    const bool okr = (S <= 0x1p+100f) && (S >= 0x1p-100f || S == 0.f);
+    float r = __builtin_amdgcn_rcpf(S);
+    r = fmaf(fmaf(-S, r, 1.0f), r, r);
+    return okr ? r : 1.0f / S;
+}
+
+// MODE 0: inference (refined depth -> out).  MODE 2: the training forward — every step's state goes to its history plane, the
+// normaliser S (and, when asked for, the taps) is published.  MODE 4: the volume-free reverse sweep G_t = stencil^T((1-m) G_{t+1}) on
+// the taps |g_j[p]| / S[p + off_j]; d0 is G_T, the history receives G_{T-1} .. G_0, (1-m) G travels.
+template <int BLEND, int MODE>
 __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepArgs a) {
     if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) return;      // the call finished: nothing to do
+    constexpr bool TRANS = MODE == 4, HIST = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int T = a.T, R = REP_TILE + 2 * T, H = a.H, W = a.W, Wv = a.Wv;
     float* cur = lds;
     float* nxt = lds + (size_t)R * R;
     const int tiles = a.tiles_x * a.tiles_y;
-    const size_t HW = (size_t)H * W;
+    const size_t HW = (size_t)H * W, plane = (size_t)a.B * HW;
     for (int t = blockIdx.x; t < a.B * tiles; t += gridDim.x) {
         const int b = t / tiles, tr = t - b * tiles, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
         const int ry0 = ty * REP_TILE - T, rx0 = tx * REP_TILE - T;       // image coordinates of region (0, 0)
         const float* __restrict__ gb = a.g + (size_t)b * a.g_bs;
         const float* __restrict__ db = a.d0 + b * HW;
         const float* __restrict__ sb = BLEND ? a.sparse + b * HW : nullptr;
+        const float* __restrict__ sib = TRANS ? a.s_in + b * HW : nullptr;
         __syncthreads();                                                   // (the previous tile's readers are done)
         for (int i = threadIdx.x; i < R * R; i += REP_THREADS) {
             const int ry = i / R, rx = i - ry * R, y = ry0 + ry, x = rx0 + rx;
             const bool in = y >= 0 && y < H && x >= 0 && x < Wv;
-            cur[i] = in ? db[(size_t)y * W + x] : 0.f;
+            float v = in ? db[(size_t)y * W + x] : 0.f;
+            if (TRANS && BLEND && in) v *= 1.f - sgnf(sb[(size_t)y * W + x]);      // the sweep starts from (1-m) G_T
+            cur[i] = v;
             nxt[i] = 0.f;
         }
         __syncthreads();
         for (int s = 1; s <= T; ++s) {
             // after step s the pixels within T - s of the tile are exact: only those are advanced
             const int lo = s, n = R - 2 * s;
+            float* const hp = HIST ? a.hist + (size_t)(s - 1) * plane + b * HW : nullptr;
             for (int i = threadIdx.x; i < n * n; i += REP_THREADS) {
                 const int ry = lo + i / n, rx = lo + i % n, y = ry0 + ry, x = rx0 + rx;
-                float u = 0.f;
+                float keep = 0.f;
                 if (y >= 0 && y < H && x >= 0 && x < Wv) {
-                    // taps as cspn3_resident derives them: tap j (row-major without the centre) = |channel 7-j| at p + off_j, 0 outside
-                    // the image (rows: [0, H); columns: [0, W) — the row padding [Wv, W) holds the caller's zeros)
-                    float av[8], qv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int lin = j < 4 ? j : j + 1, yy = y + lin / 3 - 1, xx = x + lin % 3 - 1;
-                        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                        av[j] = ok ? fabsf(gb[(size_t)(7 - j) * a.g_cs + (size_t)yy * W + xx]) : 0.f;
-                    }
-                    float S = av[7];
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) S += av[7 - k];          // the reference's channel order (CSPN_new.py:124-127)
-                    div8_shared_reciprocal(av, S, qv);
+                    const bool mine = ry >= T && ry < T + REP_TILE && rx >= T && rx < T + REP_TILE;      // a pixel of the tile itself
+                    float qv[8];
                     float m = 0.f;
-                    if (BLEND) {
-                        m = sgnf(sb[(size_t)y * W + x]);
-                        const float om = 1.f - m;                          // 0, 1 or 2: exact
+                    if (BLEND) m = sgnf(sb[(size_t)y * W + x]);
+                    if (TRANS) {
+                        // tap j = |channel j at p| x 1 / S[p + off_j] (the forward's refined reciprocal), 0 where p + off_j is outside
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) qv[j] *= om;
+                        for (int j = 0; j < 8; ++j) {
+                            const int lin = j < 4 ? j : j + 1, yy = y + lin / 3 - 1, xx = x + lin % 3 - 1;
+                            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < Wv;
+                            const float rs = ok ? rcp_as_forward(sib[(size_t)yy * W + xx]) : 0.f;
+                            qv[j] = fabsf(gb[(size_t)j * a.g_cs + (size_t)y * W + x]) * rs;
+                        }
+                    } else {
+                        // taps as cspn3_resident derives them: tap j (row-major without the centre) = |channel 7-j| at p + off_j, 0
+                        // outside the image (rows: [0, H); columns: [0, W) — the row padding [Wv, W) holds the caller's zeros)
+                        float av[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int lin = j < 4 ? j : j + 1, yy = y + lin / 3 - 1, xx = x + lin % 3 - 1;
+                            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                            av[j] = ok ? fabsf(gb[(size_t)(7 - j) * a.g_cs + (size_t)yy * W + xx]) : 0.f;
+                        }
+                        float S = av[7];
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) S += av[7 - k];          // the reference's channel order (CSPN_new.py:124-127)
+                        div8_shared_reciprocal(av, S, qv);
+                        if (MODE == 2 && mine && s == 1) {                      // published before the blend is folded in
+                            a.s_out[b * HW + (size_t)y * W + x] = S;
+                            if (a.w_out) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) a.w_out[((size_t)b * 8 + j) * HW + (size_t)y * W + x] = qv[j];
+                            }
+                        }
+                        if (BLEND) {
+                            const float om = 1.f - m;                          // 0, 1 or 2: exact
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) qv[j] *= om;
+                        }
                     }
+                    float u = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int lin = j < 4 ? j : j + 1;
                         u = fmaf(qv[j], cur[(ry + lin / 3 - 1) * R + rx + lin % 3 - 1], u);
                     }
-                    // + m * d0: a product rounded on its own, then an addition (the resident kernel keeps m * d0 in LDS) — never one FMA
-                    if (BLEND) u = __fadd_rn(u, __fmul_rn(m, db[(size_t)y * W + x]));
+                    if (TRANS) {
+                        keep = BLEND ? __fmul_rn(1.f - m, u) : u;              // (1-m) G travels, G itself goes to the history
+                    } else {
+                        // + m * d0: a product rounded on its own, then an addition (the resident kernel keeps m * d0 in LDS) — never one FMA
+                        if (BLEND) u = __fadd_rn(u, __fmul_rn(m, db[(size_t)y * W + x]));
+                        keep = u;
+                    }
+                    if (HIST && mine) hp[(size_t)y * W + x] = u;
                 }
-                nxt[ry * R + rx] = u;
+                else if (MODE == 2 && s == 1 && y >= 0 && y < H && x >= Wv && x < W && (x & ~3) < Wv && ry >= T && ry < T + REP_TILE && rx >= T && rx < T + REP_TILE) {
+                    // row padding inside the last valid quad: the resident launch stores that quad's S (and zero taps) as a whole
+                    float S = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int j = 7 - k, lin = j < 4 ? j : j + 1, yy = y + lin / 3 - 1, xx = x + lin % 3 - 1;
+                        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                        const float av = ok ? fabsf(gb[(size_t)(7 - j) * a.g_cs + (size_t)yy * W + xx]) : 0.f;
+                        S = k == 0 ? av : S + av;
+                    }
+                    a.s_out[b * HW + (size_t)y * W + x] = S;
+                    if (a.w_out) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a.w_out[((size_t)b * 8 + j) * HW + (size_t)y * W + x] = 0.f;
+                    }
+                }
+                nxt[ry * R + rx] = keep;
             }
             __syncthreads();
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
-        float* __restrict__ ob = a.out + b * HW;
-        for (int i = threadIdx.x; i < REP_TILE * REP_TILE; i += REP_THREADS) {
-            const int ly = i / REP_TILE, lx = i - ly * REP_TILE, y = ty * REP_TILE + ly, x = tx * REP_TILE + lx;
-            if (y < H && x < Wv) ob[(size_t)y * W + x] = cur[(T + ly) * R + T + lx];
+        if (!HIST) {
+            float* __restrict__ ob = a.out + b * HW;
+            for (int i = threadIdx.x; i < REP_TILE * REP_TILE; i += REP_THREADS) {
+                const int ly = i / REP_TILE, lx = i - ly * REP_TILE, y = ty * REP_TILE + ly, x = tx * REP_TILE + lx;
+                if (y < H && x < Wv) ob[(size_t)y * W + x] = cur[(T + ly) * R + T + lx];
+            }
         }
     }
 }
@@ -105,18 +167,29 @@ namespace cspn_detail {
 
 bool resident_repair_fits(int T) { return T >= 1 && (size_t)2 * (REP_TILE + 2 * T) * (REP_TILE + 2 * T) * sizeof(float) <= 160 * 1024; }
 
-int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, const unsigned* abort_word,
-                           unsigned seq, int B, int H, int W, int Wv, int T, int blend, int n_cu, void* stream) {
+int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, float* hist, float* s_out,
+                           float* w_out, const float* s_in, int mode, const unsigned* abort_word, unsigned seq, int B, int H, int W, int Wv,
+                           int T, int blend, int n_cu, void* stream) {
     if (!resident_repair_fits(T)) return fail("cspn3_forward_resident: the guard re-computes at most 54 steps (T=%d)", T);
-    RepArgs a{g, bs, cs, d0, sparse, out, abort_word, seq, B, H, W, Wv, T, ceil_div(Wv, REP_TILE), ceil_div(H, REP_TILE)};
+    if (mode != 0 && mode != 2 && mode != 4) return fail("cspn3_forward_resident: the guard has no form for this launch");
+    RepArgs a{g, bs, cs, d0, sparse, out, hist, s_out, w_out, s_in, abort_word, seq, B, H, W, Wv, T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
     const size_t lds = (size_t)2 * (REP_TILE + 2 * T) * (REP_TILE + 2 * T) * sizeof(float);
-    static std::atomic<size_t> granted[2][64];
+    static std::atomic<size_t> granted[6][64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
-    const auto kern = blend ? cspn3_resident_repair<1> : cspn3_resident_repair<0>;
-    if (lds > 64 * 1024 && granted[blend ? 1 : 0][dev & 63].load(std::memory_order_acquire) < lds) {
+    const int slot = (mode == 0 ? 0 : mode == 2 ? 2 : 4) + (blend ? 1 : 0);
+    void (*kern)(RepArgs) = nullptr;
+    switch (slot) {
+        case 0: kern = cspn3_resident_repair<0, 0>; break;
+        case 1: kern = cspn3_resident_repair<1, 0>; break;
+        case 2: kern = cspn3_resident_repair<0, 2>; break;
+        case 3: kern = cspn3_resident_repair<1, 2>; break;
+        case 4: kern = cspn3_resident_repair<0, 4>; break;
+        default: kern = cspn3_resident_repair<1, 4>; break;
+    }
+    if (lds > 64 * 1024 && granted[slot][dev & 63].load(std::memory_order_acquire) < lds) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted[blend ? 1 : 0][dev & 63].store(lds, std::memory_order_release);
+        granted[slot][dev & 63].store(lds, std::memory_order_release);
     }
     // one workgroup per CU (they loop over the tiles): the success path is n_cu workgroups that read one word and return
     int grid = B * a.tiles_x * a.tiles_y;

@@ -108,6 +108,10 @@ __device__ __forceinline__ void st4(gptr p, float4 v) {
 #ifndef CSPN_RES_HIST_NT
 #define CSPN_RES_HIST_NT 1
 #endif
+#ifndef CSPN_RES_PUBLISH_ALL
+#define CSPN_RES_PUBLISH_ALL 1      // 0: only the quads a neighbour will read are published — 6 MB less traffic per forward at config 2 but
+                                    // NOT faster (same-box A/B, profiles/r05_publish_ab.txt: 48.0 vs 47.8 us, sparse 53.9 vs 53.1): kept for A/B runs
+#endif
 __device__ __forceinline__ void st4_hist(gptr p, float4 v) {
     const v4f w = {v.x, v.y, v.z, v.w};
     if (CSPN_RES_HIST_NT) __builtin_nontemporal_store(w, reinterpret_cast<GLB v4f*>(p));
@@ -720,9 +724,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                 // registers the step loop needs — they would be spilled and reloaded from scratch every phase)
                 unsigned o0 = (unsigned)(yq0L * W + xqL);
                 asm volatile("" : "+v"(o0));
+                // -DCSPN_RES_PUBLISH_ALL=0 (round 5 experiment, not faster): only what a neighbour will READ is published — the columns / rows of this
+                // tile that lie inside an adjacent tile's depth region (its weight region + the 1-pixel ring), worked out from the
+                // neighbours' region origins exactly as they work them out themselves.  Corner neighbours read the intersection of
+                // a column band and a row band, so the union of the four bands covers all eight.  At config 2 that is 57 % of the
+                // interior quads: fewer device-scope stores to wait for before the flag, 6 MB less write traffic per forward.
+#if !CSPN_RES_PUBLISH_ALL
+                auto reg_x0 = [&](int t) { const int xx0 = t * a.tw; return max(max(0, xx0 - a.tw), min(xx0 - a.hxw, W - 4 * wq)); };
+                auto reg_y0 = [&](int t) { const int yy0 = t * a.th; return max(max(0, yy0 - a.th), min(yy0 - a.hyw, H - wr)); };
+                const int pubL = tx > 0 ? reg_x0(tx - 1) + 4 * wq + 1 : -(1 << 30);            // columns x < pubL are read by the tiles on the left
+                const int pubR = tx + 1 < a.tiles_x ? reg_x0(tx + 1) - 1 : (1 << 30);          // columns x >= pubR by the tiles on the right
+                const int pubT = ty > 0 ? reg_y0(ty - 1) + wr + 1 : -(1 << 30);                // rows y < pubT by the tiles above
+                const int pubB = ty + 1 < a.tiles_y ? reg_y0(ty + 1) - 1 : (1 << 30);          // rows y >= pubB by the tiles below
+                const bool col_read = (xqL < pubL) || (xqL + 3 >= pubR);
+#endif
 #pragma unroll
-                for (int i = 0; i < NQ; ++i)
-                    if ((interior >> i) & 1u) st4_dev(xout, o0 + (unsigned)(i * W), own[i][0], own[i][1], own[i][2], own[i][3]);
+                for (int i = 0; i < NQ; ++i) {
+#if !CSPN_RES_PUBLISH_ALL
+                    const bool read = col_read || (yq0L + i < pubT) || (yq0L + i >= pubB);
+#else
+                    const bool read = true;
+#endif
+                    if (((interior >> i) & 1u) && read) st4_dev(xout, o0 + (unsigned)(i * W), own[i][0], own[i][1], own[i][2], own[i][3]);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's device-scope stores have landed
             __syncthreads();                                       // ... and so have everybody else's in the workgroup
@@ -739,7 +763,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
                             wg_bad = 1;
                             break;
                         }
-                        if (spins > a.spin_limit) {                // a neighbour never became resident / finished: give up
+                        if (spins >= a.spin_limit) {                // a neighbour never became resident / finished: give up
                             __hip_atomic_store(a.status, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             wg_bad = 1;
                             break;
@@ -1108,8 +1132,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     a.dbg = rp.debug_stamps;
     const bool clean = regions_inside_image(g, H, W, a.Wv, T);
     // (refused rather than ignored: a host that asked for the guard relies on `out` being complete for GPU-side consumers)
-    if (rp.guard && (mode != 0 || !out || !cspn_detail::resident_repair_fits(T)))
-        return fail("cspn3_forward_resident: plan->guard serves plain inference calls (no history, no scoring, CSPN_new weights) of T <= 54 steps");
+    if (rp.guard && ((mode != 0 && mode != 2 && mode != 7) || (mode == 0 && !out) || !cspn_detail::resident_repair_fits(T)))
+        return fail("cspn3_forward_resident: plan->guard serves the unscored CSPN_new forms (inference, training forward, volume-free reverse sweep) of T <= 54 steps");
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
@@ -1127,7 +1151,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         if (!ok) return 0;
     }
     if (rp.guard)
-        return cspn_detail::resident_repair_launch(a.g, bs, cs, a.d0, a.sparse, a.out, a.status, seq, B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st);
+        return cspn_detail::resident_repair_launch(a.g, bs, cs, a.d0, a.sparse, a.out, a.hist, a.s_out, a.w_out, a.s_in, mode == 7 ? 4 : mode, a.status, seq,
+                                                   B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st);
     return 1;
 }
 

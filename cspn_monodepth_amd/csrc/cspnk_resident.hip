@@ -526,7 +526,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                             wg_bad = 1;
                             break;
                         }
-                        if (spins > a.spin_limit) {                // a neighbour never became resident / finished: give up
+                        if (spins >= a.spin_limit) {                // a neighbour never became resident / finished: give up
                             __hip_atomic_store(a.status, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             wg_bad = 1;
                             break;

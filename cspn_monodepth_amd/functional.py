@@ -933,7 +933,9 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
         key = (B, H, W, ws_kind, state_bytes)
         work = st["work"].get(key)
         if work is None:
-            if len(st["work"]) > 16:
+            if len(st["work"]) > 16:                    # (more than 16 shapes: start the cache over — behind whatever still uses it)
+                if st["last_stream"] is not None and not torch.cuda.is_current_stream_capturing():
+                    st["last_stream"].synchronize()
                 st["work"].clear()
             work = st["work"][key] = torch.zeros((ws_bytes_fn(),), dtype=torch.uint8, device=dev)
         with _device_guard(dev):
@@ -966,6 +968,8 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
                 st["last_raw"] = raw
                 st["dirty"] = True
                 st["last_reports"] = bool(reports_done)
+                if reports_done and not guarded:        # an unguarded training-form launch: the end-of-backward check must look at it
+                    st["need_bwd_check"] = True
                 if reports_done:                        # training-form launches store `seq` to the completion word
                     st["last_seq"] = seq
                 _journal_add(dev, st, _JournalEntry(redo, out, inputs, what, guarded), cur)
@@ -1028,14 +1032,15 @@ def transposed_resident_guidance(guidance, S, g_T, sparse_f32, T, valid_w=0):
     B, H, W = g_T.shape
     L = _lib.lib()
     ghist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
-    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1])
+    guard = int(_RESIDENT_GUARD and int(T) <= _GUARD_MAX_T)
+    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1], guard=guard)
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspn3_transposed_resident_guidance(_p(guidance), guidance.stride(0), guidance.stride(1), _p(S), _p(g_T), _p(sparse_f32),
                                                     _p(ghist), _p(work), seq, host_err_ptr, B, H, W, int(valid_w), int(T),
                                                     int(sparse_f32 is not None), None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True, guarded=bool(guard))
     _lib.check(ok, "cspn3_transposed_resident_guidance")
     return ghist
 
@@ -1088,7 +1093,7 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     tg, acc = score if score is not None else (None, None)
     rp = None
-    guard = int(_RESIDENT_GUARD and score is None and not keep_history and int(T) <= _GUARD_MAX_T) if guard is None else int(guard)
+    guard = int(_RESIDENT_GUARD and score is None and int(T) <= _GUARD_MAX_T) if guard is None else int(guard)
     if steps_per_phase or spin_limit or debug_stamps is not None:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
@@ -1377,6 +1382,9 @@ def _check_resident_at_end_of_backward(dev):
     st = _RES.get(dev.index)
     if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing() or os.environ.get("CSPN_BWD_CHECK") == "off":
         return                     # (CSPN_BWD_CHECK=off: A/B switch for measurements; the next resident launch still raises)
+    if not st.get("need_bwd_check"):
+        return                     # every training-form launch since the last check carried its device-side guard (round 5): whatever
+    st["need_bwd_check"] = False   # the loss and the optimiser read is complete by stream order — nothing for the host to wait for
     cp = _ResidentCheckpoint(dev)
     if st.get("last_reports"):     # the newest launch is the one the checkpoint waits for: everything issued so far is covered
         st["dirty"] = False        # (a later inference launch does not report completion: the next ensure_resident_ok still waits)

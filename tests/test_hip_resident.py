@@ -541,14 +541,19 @@ def test_journal_does_not_pin_batches(c_oracle):
     m = pkg.CSPN_new.AffinityPropagate(24, 3)
     st = F._resident_state(gt.device)
     with torch.no_grad(), resident("on"):
-        for _ in range(40):
+        with guard(False):                          # host-repaired calls: their entries hold the call's tensors
+            for _ in range(40):
+                m(gt, dt)
+            assert len(st["journal"]) <= F._JOURNAL_MAX
+            torch.cuda.synchronize()
             m(gt, dt)
-        assert len(st["journal"]) <= F._JOURNAL_MAX
-        torch.cuda.synchronize()
-        m(gt, dt)
-        assert len(st["journal"]) <= 2, len(st["journal"])
+            assert len(st["journal"]) <= 2, len(st["journal"])
+            F.ensure_resident_ok()
+            assert not st["journal"]
+        for _ in range(20):                         # guarded calls (the default for plain inference): nothing is kept alive at all
+            m(gt, dt)
+        assert all(e.guarded and e.out is None and not e.inputs for e in st["journal"])
         F.ensure_resident_ok()
-        assert not st["journal"]
 
 
 def test_contended_device_results_equal_uncontended(c_oracle):
@@ -626,11 +631,12 @@ def test_contended_device_results_equal_uncontended(c_oracle):
 
 @pytest.mark.parametrize("where", ["forward", "reverse_sweep"])
 def test_timeout_in_a_training_step_raises_before_backward_returns(where, c_oracle):
-    """A training forward (history kept) or the backward's reverse sweep that timed out must raise before `.backward()`
-    returns — i.e. before any optimiser step could apply the gradients (functional._check_resident_at_end_of_backward)."""
+    """WITHOUT the device-side guard (set_resident_guard(False); also what the K x K training forms rely on): a training forward
+    (history kept) or the backward's reverse sweep that timed out must raise before `.backward()` returns — i.e. before any
+    optimiser step could apply the gradients (functional._check_resident_at_end_of_backward)."""
     gt, dt, _ = _config2(c_oracle, seed=311, B=3)
     m = pkg.CSPN_new.AffinityPropagate(24, 3)
-    with resident("on"):
+    with resident("on"), guard(False):
         for broken in (True, False):
             g_ = gt.clone().requires_grad_(True)
             d_ = dt.clone().requires_grad_(True)
@@ -646,6 +652,42 @@ def test_timeout_in_a_training_step_raises_before_backward_returns(where, c_orac
                 torch.cuda.synchronize()
                 assert bool(torch.isfinite(g_.grad).all()) and bool(torch.isfinite(d_.grad).all())
     torch.cuda.synchronize()
+    F.check_resident_errors()
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 228, 304), (24, 228, 304), (8, 352, 1216), (2, 61, 76)], ids=["nyu_b3", "config2", "kitti_b8", "small"])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_guarded_training_step_survives_timeouts(B, H, W, sparse, c_oracle):
+    """Round 5: the training forms carry the device-side guard as well (cspn_resident_plan.guard: the training forward and the
+    volume-free reverse sweep have re-computation forms in csrc/cspn_repair.hip).  Every tile of the forward with history, then of
+    the reverse sweep, is forced to give up: no exception, and the refined depth, the history planes the backward reads and both
+    gradients are the bits of an undisturbed step — the loss and the optimiser never see a partial result, and the host does
+    not wait at the end of the backward pass any more."""
+    import warnings
+    T = 24
+    g, d, s = c_oracle.synthetic_inputs(600 + B, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    cot = dev(c_oracle.hash_normal(601, 9, (B, 1, H, W)))
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+
+    def step(limit_fwd, limit_bwd):
+        g_, d_ = dev(g).requires_grad_(True), dev(d).requires_grad_(True)
+        with spin_limit(limit_fwd):
+            out = m(g_, d_, dev(s))
+        with spin_limit(limit_bwd):
+            out.backward(cot)
+        return out.detach(), g_.grad, d_.grad
+
+    with resident("on"), guard(True), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        ref = step(0, 0)
+        torch.cuda.synchronize()
+        assert F.resident_fallbacks() == 0
+        for lf, lb in ((1, 0), (0, 1), (1, 1)):
+            got = step(lf, lb)
+            for a, b_, what in zip(got, ref, ("refined depth", "dL/dguidance", "dL/ddepth")):
+                assert bits_equal(a, b_, T=T, sparse=sparse, which="%s, time-out forced in %s" % (what, "forward" if lf else "sweep"))
+        F.ensure_resident_ok()                                  # the host learns about the events; nothing to raise
+        assert F.resident_fallbacks() >= 1
     F.check_resident_errors()
 
 
