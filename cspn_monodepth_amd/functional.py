@@ -258,11 +258,11 @@ class _device_guard(object):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return torch._C._cuda_getCurrentRawStream(dev.index)       # (a plain int: the argtypes say c_void_p; no Stream object per call)
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()                  # (a plain int, as above: ~0.4 us per argument less than a c_void_p object)
 
 
 def _plane(t, B, H, W, name):
@@ -626,22 +626,14 @@ def _poison_mask(t):
     return (t.view(torch.int32) == POISON_F32) if t.dtype == torch.float32 else (t.view(torch.int16) == POISON_F16)
 
 
-def _nothing():
-    pass
-
-
 class _JournalEntry(object):
     """One resident launch that may still turn out to have timed out.  redo: re-runs the call on the multi-launch schedule into
     the same output tensor (None: a training-form launch / anything that cannot be repaired after the fact); out: the tensor a
     failed tile poisons; inputs: the tensors the repair would read, with their version counters at launch time — a repair from
     inputs the caller has since overwritten in place would silently produce the result of ANOTHER batch."""
-    __slots__ = ("redo", "out", "inputs", "versions", "nbytes", "what", "guarded")
+    __slots__ = ("redo", "out", "inputs", "versions", "nbytes", "what")
 
-    def __init__(self, redo, out=None, inputs=(), what="resident launch", guarded=False):
-        # guarded: the launch carried its own device-side repair (cspn_resident_plan.guard) — nothing to redo, no tensor kept alive
-        self.guarded = guarded
-        if guarded:
-            redo, out, inputs = _nothing, None, ()
+    def __init__(self, redo, out=None, inputs=(), what="resident launch"):
         self.redo, self.out, self.what = redo, out, what
         self.inputs = tuple(t for t in inputs if t is not None)
         self.versions = tuple(t._version for t in self.inputs)
@@ -673,12 +665,11 @@ def _recover(dev, st):
         training = any(e.redo is None for e in journal)
         _note_fallback(training=training)
         stale = []
-        repaired = 0
+        # launches that carried their own guard (cspn_resident_plan.guard) left no entry: if it was one of them, its guard kernel has
+        # re-computed the result on the stream already
+        repaired, st["guarded_pending"] = st.get("guarded_pending", 0), 0
         with _device_guard(dev):
             for e in journal:
-                if e.guarded:
-                    repaired += 1                  # (if it was this one, its guard kernel has re-computed it on the stream)
-                    continue
                 if e.redo is None or e.out is None or not _holds_poison(e.out):
                     continue                       # finished cleanly (or cannot be looked at: handled below)
                 if not e.inputs_untouched():
@@ -802,6 +793,7 @@ def _journal_clear(st):
     del st["journal"][:]
     st["lost"] = False
     st["jbytes_since_mark"] = 0
+    st["guarded_pending"] = 0
     st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
     st["marks"] = []
 
@@ -834,7 +826,7 @@ def ensure_resident_ok(dev=None):
             st["dirty"] = False
         if st["host_err_np"][0] != 0:
             _recover(torch.device("cuda", idx), st)
-        elif st["journal"]:
+        elif st["journal"] or st.get("guarded_pending"):
             with st["lock"]:
                 if st["host_err_np"][0] == 0 and not st["dirty"]:      # everything issued so far has finished cleanly
                     _journal_clear(st)
@@ -912,34 +904,37 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
     the graph's private pool (it lives as long as the graph).  Replays are ordered by their stream like any launch; the
     caller must not replay two graphs holding resident launches concurrently on one device (they could not both be
     co-resident: the bounded wait would flag it)."""
-    L = _lib.lib()
     log = _EVENT_LOG
     if log is not None and not log.take():
         log = None
-    if ws_bytes_fn is None:
-        ws_bytes_fn = lambda: L.cspn3_resident_workspace_bytes(B, H, W)      # noqa: E731
-    if torch.cuda.is_current_stream_capturing():
-        nbytes = ws_bytes_fn()
+    idx = dev.index
+    if torch._C._cuda_isCurrentStreamCapturing():
+        nbytes = ws_bytes_fn() if ws_bytes_fn is not None else _lib.lib().cspn3_resident_workspace_bytes(B, H, W)
         work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         work[(2 * B * H * W * state_bytes + 15) & ~15:].zero_()
         st = _resident_state(dev)
         with _device_guard(dev):
             cur = torch.cuda.current_stream(dev)
-            return launch(work, _RES_SEQ_STEP, st["host_err_ptr"], ctypes.c_void_p(cur.cuda_stream))
-    st = _resident_state(dev)
+            return launch(work, _RES_SEQ_STEP, st["host_err_ptr"], cur.cuda_stream)
+    st = _RES.get(idx) or _resident_state(dev)
     with st["lock"]:
         if st["host_err_np"][0] != 0:
             _recover(dev, st)                           # repairs the journaled calls, or raises
-        key = (B, H, W, ws_kind, state_bytes)
-        work = st["work"].get(key)
+        work = st["work"].get((B, H, W, ws_kind, state_bytes))
         if work is None:
             if len(st["work"]) > 16:                    # (more than 16 shapes: start the cache over — behind whatever still uses it)
-                if st["last_stream"] is not None and not torch.cuda.is_current_stream_capturing():
+                if st["last_stream"] is not None:
                     st["last_stream"].synchronize()
                 st["work"].clear()
-            work = st["work"][key] = torch.zeros((ws_bytes_fn(),), dtype=torch.uint8, device=dev)
-        with _device_guard(dev):
-            raw = torch._C._cuda_getCurrentRawStream(dev.index)       # (a Stream object per call costs ~1.5 us of the ~20 us call)
+            nbytes = ws_bytes_fn() if ws_bytes_fn is not None else _lib.lib().cspn3_resident_workspace_bytes(B, H, W)
+            work = st["work"][(B, H, W, ws_kind, state_bytes)] = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        # (this function is most of the host time of a small call: no context-manager object when `dev` is current already, raw
+        #  stream handles, no journal entry for a launch that carries its own guard — tools/probes/r05_host_timing_train.py)
+        ctx = None if torch._C._cuda_getDevice() == idx else torch.cuda.device(dev)
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            raw = torch._C._cuda_getCurrentRawStream(idx)
             if raw == st.get("last_raw"):
                 cur = st["last_stream"]
             else:
@@ -959,7 +954,7 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
             if log is not None:
                 ev0, ev1 = log.pair()
                 ev0.record(cur)
-            ok = launch(work, seq, st["host_err_ptr"], ctypes.c_void_p(raw))
+            ok = launch(work, seq, st["host_err_ptr"], raw)
             if log is not None:
                 ev1.record(cur)
                 log.append((ev0, ev1, 1, T))
@@ -967,12 +962,18 @@ def _resident_launch(dev, B, H, W, T, launch, ws_kind="3", state_bytes=4, ws_byt
                 st["last_stream"] = cur
                 st["last_raw"] = raw
                 st["dirty"] = True
-                st["last_reports"] = bool(reports_done)
-                if reports_done and not guarded:        # an unguarded training-form launch: the end-of-backward check must look at it
-                    st["need_bwd_check"] = True
+                st["last_reports"] = reports_done
                 if reports_done:                        # training-form launches store `seq` to the completion word
                     st["last_seq"] = seq
-                _journal_add(dev, st, _JournalEntry(redo, out, inputs, what, guarded), cur)
+                    if not guarded:                     # ... and an unguarded one must be looked at by the end-of-backward check
+                        st["need_bwd_check"] = True
+                if guarded:
+                    st["guarded_pending"] = st.get("guarded_pending", 0) + 1      # its guard kernel repairs it on the stream: no entry, no tensor kept alive
+                else:
+                    _journal_add(dev, st, _JournalEntry(redo, out, inputs, what), cur)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
     return ok
 
 
@@ -1025,15 +1026,18 @@ def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
     return ghist
 
 
-def transposed_resident_guidance(guidance, S, g_T, sparse_f32, T, valid_w=0):
+def transposed_resident_guidance(guidance, S, g_T, sparse_f32, T, valid_w=0, _plan=None):
     """The same reverse sweep without a tap volume: the transposed taps |g_j[p]| / S[p + off_j] are rebuilt from the raw guidance
     and the normaliser S the training forward published (include/cspn_hip.h cspn3_transposed_resident_guidance)."""
-    dev = _require_device(guidance, S, g_T, sparse_f32)
     B, H, W = g_T.shape
     L = _lib.lib()
+    if _plan is not None:                              # CSPN3Function's fast path: validated with the forward, guarded plan in hand
+        dev, guard, rp = guidance.device, 1, _plan
+    else:
+        dev = _require_device(guidance, S, g_T, sparse_f32)
+        guard = int(_RESIDENT_GUARD and int(T) <= _GUARD_MAX_T)
+        rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1], guard=guard)
     ghist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
-    guard = int(_RESIDENT_GUARD and int(T) <= _GUARD_MAX_T)
-    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1], guard=guard)
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspn3_transposed_resident_guidance(_p(guidance), guidance.stride(0), guidance.stride(1), _p(S), _p(g_T), _p(sparse_f32),
@@ -1073,7 +1077,7 @@ def pac_transposed_resident(wk, g_T, sparse, T):
 
 
 def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None,
-                     keep_history=False, publish_weights=True, guard=None):
+                     keep_history=False, publish_weights=True, guard=None, _plan=None):
     """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it.
 
     keep_history=True is the training forward: returns (d_T [view of history[T-1]], history [T,B,H,W], w8 [B,8,H,W],
@@ -1094,7 +1098,9 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
     tg, acc = score if score is not None else (None, None)
     rp = None
     guard = int(_RESIDENT_GUARD and score is None and int(T) <= _GUARD_MAX_T) if guard is None else int(guard)
-    if steps_per_phase or spin_limit or debug_stamps is not None:
+    if _plan is not None and not _RESIDENT_SPIN_LIMIT:
+        rp = _plan                                     # the caller's cached (guarded) plan: CSPN3Function's fast path
+    elif steps_per_phase or spin_limit or debug_stamps is not None:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
         rp.spin_limit = int(spin_limit)
@@ -1399,17 +1405,46 @@ class _NoGradCtx(object):
     needs_input_grad = (False,) * 8
 
 
+_TRAIN_FAST = {}       # call signature -> (cached guarded resident plan, blend): CSPN3Function's resident training form, checks done once
+
+
+def _train_fast_key(guidance, blur_depth, sparse_depth, prop_time, plan, valid_w):
+    """Everything the slow path's checks depend on that does not change from step to step in a training loop; what can
+    (contiguity, alignment, the module-level switches) is re-checked per call."""
+    if plan is not None or _DEFAULT_PLANS or _RESIDENT_MODE == "off" or _RESIDENT_SPIN_LIMIT or not _RESIDENT_GUARD:
+        return None
+    return (guidance.shape, guidance.stride(), guidance.dtype, blur_depth.shape, blur_depth.dtype,
+            None if sparse_depth is None else (sparse_depth.shape, sparse_depth.dtype), prop_time, valid_w, _RESIDENT_MODE, guidance.device)
+
+
 class CSPN3Function(torch.autograd.Function):
     """3x3 variant, forward + hand-written backward (SURVEY.md §3.2 closed form)."""
 
     @staticmethod
     def forward(ctx, guidance, blur_depth, sparse_depth, prop_time, plan, valid_w=0):
         B, C, H, W = guidance.shape
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        # Fast path of a training loop (round 5: the step was HOST-bound, 217 us of host time for 209 us of kernels): a call whose
+        # signature took the weight-resident training form before goes straight to it — no re-validation, no plan look-ups.
+        key = _train_fast_key(guidance, blur_depth, sparse_depth, prop_time, plan, valid_w) if need_grad else None
+        hit = _TRAIN_FAST.get(key) if key is not None else None
+        if (hit is not None and blur_depth.is_contiguous() and (sparse_depth is None or sparse_depth.is_contiguous())
+                and not ((guidance.data_ptr() | blur_depth.data_ptr() | (0 if sparse_depth is None else sparse_depth.data_ptr())) & 15)
+                and blur_depth.device == guidance.device and (sparse_depth is None or sparse_depth.device == guidance.device)
+                and not torch._C._cuda_isCurrentStreamCapturing()):
+            d0 = blur_depth.view(B, H, W)
+            sp = None if sparse_depth is None else sparse_depth.view(B, H, W)
+            out, hist, w8, S = forward_resident(guidance, d0, sp, prop_time, hit[1], valid_w=valid_w, keep_history=True,
+                                                publish_weights=os.environ.get("CSPN_TRAIN_VOLUME", "0") == "1", guard=1, _plan=hit[0])
+            ctx.save_for_backward(guidance, w8, S, d0, sp, hist)
+            ctx.prop_time, ctx.plan, ctx.valid_w = prop_time, None, valid_w
+            ctx.in_shape = tuple(blur_depth.shape)
+            ctx.fast = hit
+            return out.unsqueeze(1)
         d0 = _plane(blur_depth, B, H, W, "blur_depth")
         sp = _plane(sparse_depth, B, H, W, "sparse_depth")
         if d0.dtype != guidance.dtype or (sp is not None and sp.dtype != guidance.dtype):
             raise TypeError("guidance / blur_depth / sparse_depth must share one dtype")
-        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         blend = BLEND_SPARSE if sp is not None else BLEND_NONE
         if not need_grad and resident_supported(guidance, d0, sp, prop_time, plan) is not None:
             # inference, weight-resident: one launch for all T steps, no tap volume at all
@@ -1425,6 +1460,13 @@ class CSPN3Function(torch.autograd.Function):
             #  CSPN_TRAIN_VOLUME=1 keeps it, for A/B runs)
             out, hist, w8, S = forward_resident(g, d0, sp, prop_time, blend, valid_w=valid_w, keep_history=True,
                                                 publish_weights=os.environ.get("CSPN_TRAIN_VOLUME", "0") == "1")
+            if key is not None and prop_time <= _GUARD_MAX_T and blur_depth.dim() == 4 and (sparse_depth is None or sparse_depth.dim() == 4):
+                # remember: this signature is served by the resident training form (with the guard: no host check at the end of backward)
+                cp = _with_spin_limit(_resident_plan_cached(B, H, W, int(prop_time), int(blend), guidance.device)[1], guard=1)
+                if cp is not None:
+                    if len(_TRAIN_FAST) > 256:
+                        _TRAIN_FAST.clear()
+                    _TRAIN_FAST[key] = (cp, blend)
         elif need_grad and _FROM_GUIDANCE and prop_time > 0 and from_guidance_supported(guidance, d0, sp, plan):
             # training: the first launch derives the weights, publishes them and S for the backward, and the loop keeps
             # the T depth planes — one pass over the guidance instead of a prepare pass + a re-read of the volume
@@ -1446,6 +1488,28 @@ class CSPN3Function(torch.autograd.Function):
         B, C, H, W = g.shape
         T = ctx.prop_time
         L = _lib.lib()
+        fast = getattr(ctx, "fast", None)
+        if (fast is not None and w8 is None and grad_out.dtype == torch.float32 and grad_out.is_contiguous() and not (grad_out.data_ptr() & 15)
+                and _RESIDENT_MODE != "off" and _RESIDENT_GUARD and not _RESIDENT_SPIN_LIMIT and not _DEFAULT_PLANS
+                and not torch._C._cuda_isCurrentStreamCapturing()):
+            # the forward took the fast path: same tensors, same checks — volume-free reverse sweep + fused tail, straight away
+            g_T = grad_out.view(B, H, W)
+            ghist = transposed_resident_guidance(g, S, g_T, sp, T, ctx.valid_w, _plan=fast[0])
+            gg = torch.empty_like(g)
+            gd0 = torch.empty((B, H, W), dtype=torch.float32, device=g.device)
+            dev_switch = None if torch._C._cuda_getDevice() == g.device.index else torch.cuda.device(g.device)
+            if dev_switch is not None:
+                dev_switch.__enter__()
+            try:
+                ok = L.cspn3_backward_tail(d0.data_ptr(), hist.data_ptr(), g_T.data_ptr(), ghist.data_ptr(), _p(sp), g.data_ptr(), g.stride(0),
+                                           g.stride(1), C, None, S.data_ptr(), gg.data_ptr(), gd0.data_ptr(), CSPN_F32, B, H, W, T,
+                                           torch._C._cuda_getCurrentRawStream(g.device.index))
+            finally:
+                if dev_switch is not None:
+                    dev_switch.__exit__(None, None, None)
+            _lib.check(ok, "cspn3_backward_tail")
+            return (gg if ctx.needs_input_grad[0] else None, gd0.view(ctx.in_shape) if ctx.needs_input_grad[1] else None,
+                    None, None, None, None)
         g_T, ghist = _reverse_sweep(w8, 3, T, sp, grad_out.contiguous().float(), ctx.plan, ctx.valid_w, guidance_S=(g, S))
         _check_resident_at_end_of_backward(g.device)
         gg = torch.empty_like(g)
@@ -1582,14 +1646,15 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
         key = (guidance.shape, guidance.stride(), guidance.dtype, blur_depth.shape, blur_depth.dtype,
                None if sparse_depth is None else (sparse_depth.shape, sparse_depth.dtype), target.shape, target.dtype,
                acc.shape, int(prop_time), _RESIDENT_MODE, guidance.device)
-        if (_SCORED_FAST.get(key) and blur_depth.is_contiguous() and target.is_contiguous() and acc.is_contiguous()
+        fast_plan = _SCORED_FAST.get(key)
+        if (fast_plan is not None and blur_depth.is_contiguous() and target.is_contiguous() and acc.is_contiguous()
                 and (sparse_depth is None or sparse_depth.is_contiguous())
                 and not ((guidance.data_ptr() | blur_depth.data_ptr() | target.data_ptr() |
                           (0 if sparse_depth is None else sparse_depth.data_ptr())) & 15)
                 and blur_depth.device == target.device == guidance.device and (sparse_depth is None or sparse_depth.device == guidance.device)):
             with torch.no_grad():
                 return forward_resident(guidance, blur_depth, sparse_depth, prop_time, BLEND_NONE if sparse_depth is None else BLEND_SPARSE,
-                                        score=(target, acc)).unsqueeze(1)
+                                        score=(target, acc), guard=0, _plan=fast_plan).unsqueeze(1)
     dev = _require_device(guidance, blur_depth, sparse_depth, target)
     W0 = guidance.shape[-1]
     pad = _row_padding(W0, plan)
@@ -1608,7 +1673,7 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
             if key is not None and not pad and blur_depth.dim() == 4 and target.dim() == 4 and (sparse_depth is None or sparse_depth.dim() == 4):
                 if len(_SCORED_FAST) > 256:
                     _SCORED_FAST.clear()
-                _SCORED_FAST[key] = True
+                _SCORED_FAST[key] = _resident_plan_cached(B, H, W, int(prop_time), int(blend), guidance.device)[1]
             return out.unsqueeze(1)[..., :W0]
         if (_FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan) and guidance.dtype == d0.dtype
                 and tg.dtype == d0.dtype and tg.data_ptr() % 16 == 0):

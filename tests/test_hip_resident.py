@@ -174,12 +174,16 @@ def test_resident_timeout_is_repaired_not_a_hang(c_oracle):
     B, H, W, T = 24, 228, 304, 24
     g, d, _ = c_oracle.synthetic_inputs(99, B, H, W, 12, None)
     gt, dt = dev(g), dev(d)[:, 0].contiguous()
+    F.ensure_resident_ok()                                  # an empty journal: the launch below is not the one a full journal waits for
     with torch.no_grad():
         with resident("off"):
             ref = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dev(d))
         broken = F.forward_resident(gt, dt, None, T, 0, spin_limit=1, guard=0)
         torch.cuda.synchronize()
-        assert bool(torch.isnan(broken).any()) and F._holds_poison(broken) and F.resident_fallbacks() == 0     # poisoned, and nobody has looked yet
+        if F.resident_fallbacks() == 0:                                 # nobody has looked yet: the tiles that gave up read as NaN,
+            assert bool(torch.isnan(broken).any()) and F._holds_poison(broken)      # with the payload the host recognises
+        # (the host may have looked already: recording the call's completion mark can take longer than the 20 us the launch needs
+        #  to give up, and the journal then repairs at once)
         out = F.forward_resident(gt, dt, None, T, 0)                   # finds the error word, repairs `broken`, then runs
         torch.cuda.synchronize()
     assert F.resident_fallbacks() == 1
@@ -552,7 +556,7 @@ def test_journal_does_not_pin_batches(c_oracle):
             assert not st["journal"]
         for _ in range(20):                         # guarded calls (the default for plain inference): nothing is kept alive at all
             m(gt, dt)
-        assert all(e.guarded and e.out is None and not e.inputs for e in st["journal"])
+        assert not st["journal"] and st["guarded_pending"] == 20    # counted, not kept: no entry, no tensor reference
         F.ensure_resident_ok()
 
 
