@@ -145,7 +145,7 @@ constexpr int RES_PP = 16352;
 // exchange, blend, metrics, history planes) is the same recurrence.  MODE 2 publishes the softmax taps as the [B,8,H,W] volume the
 // backward streams (no S: the softmax backward does not need one); the reverse sweep is the plain MODE 3 on that volume.
 template <int NQ, int NTHREADS, int BLEND, int MODE, int CLEAN, int PAC = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void cspn3_resident(const ResArgs a) {
+__global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const ResArgs a) {
     static_assert(!PAC || MODE <= 2, "the softmax-weight form has no transposed sweep of its own (the published volume feeds MODE 3)");
     constexpr int R = 1, NT = 8, WIN = 6;
     // MODE 3: the backward's reverse sweep  G_t = stencil^T((1-m) G_{t+1})  as the same recurrence on the TRANSPOSED taps:
@@ -848,6 +848,7 @@ struct ResGeom {
     int imgs_per_launch, launches;
     size_t lds_bytes;
     double cost;
+    int threads = RES_THREADS;      // 512, or 1024 with one quad per thread (four wavefronts per SIMD: small shards, round 5)
 };
 
 int cu_count() {
@@ -864,8 +865,23 @@ int cu_count() {
 
 // LDS of one workgroup: buffer 0 in the first RES_PP floats, buffer 1 behind it, then the private m * d0 quads (sparse
 // blend) and the 10 x 16 partial sums of the fused metrics.
-size_t res_lds_bytes(int dr, int ls, int nq, int blend) {
-    return ((size_t)RES_PP + (size_t)dr * ls + (size_t)(blend ? 1 : 0) * RES_THREADS * nq * 4 + 16 * 10) * sizeof(float);
+size_t res_lds_bytes(int dr, int ls, int nq, int blend, int threads = RES_THREADS) {
+    return ((size_t)RES_PP + (size_t)dr * ls + (size_t)(blend ? 1 : 0) * threads * nq * 4 + 16 * 10) * sizeof(float);
+}
+
+// Row stride (floats) of a depth buffer in LDS: 4 wq + 8 at least ([4 pad incl. ring][wq quads][ring + pad]).  Round 5 (-DCSPN_RES_LS_SWIZZLE=0
+// for A/B; same-box, profiles/r05_swizzle_ab.txt: NYU B = 3 20.8 -> 20.1 us per scored forward, the other shapes within noise): the smallest such stride for which the next strip of a thread column (NQ rows further down) continues the bank
+// sequence of this one inside a wavefront — NQ ls = 4 wq (mod 64 dwords) — so that the 16 lanes of a ds_read_b128 / ds_write_b128
+// pass that straddle two strips do not share banks (SQ counters of round 4: 16.5 % of the LDS cycles were bank conflicts).
+#ifndef CSPN_RES_LS_SWIZZLE
+#define CSPN_RES_LS_SWIZZLE 1
+#endif
+int res_row_stride(int wq, int nq, int dr) {
+    const int lo = 4 * wq + 8;
+    if (!CSPN_RES_LS_SWIZZLE) return lo;
+    for (int cand = lo; cand < lo + 64; cand += 4)
+        if ((((nq * cand - 4 * wq) % 64) + 64) % 64 == 0 && (size_t)dr * cand <= (size_t)RES_PP) return cand;
+    return lo;
 }
 
 // Mirror of the kernel's region placement: does every region of every tile lie inside the (valid part of the) image?
@@ -891,8 +907,10 @@ bool regions_inside_image(const ResGeom& g, int H, int W, int Wv, int T) {
 
 // Tiling of one image for the resident kernel: every workgroup owns a tw x th tile + (S-1) halo; a launch holds
 // imgs_per_launch whole images on at most `ncu` workgroups.  Cost model: launches x (quads per thread + latency floor).
-bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_user, ResGeom* best) {
+bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_user, ResGeom* best, int threads = RES_THREADS) {
     if (W % 4 != 0 || ncu < 1 || T < 1) return false;
+    if (threads != 1024) threads = RES_THREADS;
+    const int max_nq = threads == 1024 ? 1 : RES_MAX_NQ;       // 1024 threads = 128 VGPRs: one quad's weights per thread
     bool found = false;
     // phase lengths 12 / 8 / 6 / 4: twelve (one exchange at T = 24) wins on small shards whose tiles stay at two quads per
     // thread (NYU B = 6: 22.2 vs 23.9 us), eight everywhere else (tools/probes/resident_s_sweep.py)
@@ -906,7 +924,7 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
             if (tx > 1 && (tw < 16 || ceil_div(W, tw) != tx)) continue;
             if (phases > 1 && tx > 1 && tw < 2 * hxw) continue;                   // the (shifted) halo must come from adjacent tiles only
             const int wq = (tw + 2 * hxw) / 4;
-            if (wq > RES_THREADS) continue;
+            if (wq > threads) continue;
             for (int ty = 1; ty <= 64; ++ty) {
                 const int th = ceil_div(H, ty);
                 if (ty > 1 && (th < 4 || ceil_div(H, th) != ty)) continue;
@@ -914,12 +932,12 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
                 const int tiles = tx * ty;
                 if (tiles > ncu) continue;
                 const int wr = th + 2 * hyw;
-                const int rows_per_thread_col = RES_THREADS / wq;                 // strips per quad column
+                const int rows_per_thread_col = threads / wq;                     // strips per quad column
                 const int nq = ceil_div(wr, rows_per_thread_col);
-                if (nq > RES_MAX_NQ) continue;
-                const int dr = wr + 2, ls = 4 * wq + 8;
+                if (nq > max_nq) continue;
+                const int dr = wr + 2, ls = res_row_stride(wq, nq, dr);
                 if ((size_t)dr * ls > (size_t)RES_PP) continue;                      // one depth buffer per RES_PP slot
-                const size_t ldsb = res_lds_bytes(dr, ls, nq, blend);
+                const size_t ldsb = res_lds_bytes(dr, ls, nq, blend, threads);
                 if (ldsb > 160 * 1024) continue;
                 int ipl = ncu / tiles;
                 if (ipl > B) ipl = B;
@@ -934,6 +952,7 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
                 if (!found || cost < best->cost) {
                     found = true;
                     *best = ResGeom{Se, tx, ty, tw, th, nq, wq, wr, hxw, hyw, dr, ls, ipl, launches, ldsb, cost};
+                    best->threads = threads;
                 }
             }
         }
@@ -941,9 +960,9 @@ bool resident_geometry(int B, int H, int W, int T, int blend, int ncu, int S_use
     return found;
 }
 
-template <int NQ, int BLEND, int MODE, int CLEAN, int PAC = 0>
+template <int NQ, int BLEND, int MODE, int CLEAN, int PAC = 0, int NTH = RES_THREADS>
 int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspn3_resident<NQ, RES_THREADS, BLEND, MODE, CLEAN, PAC>;
+    constexpr auto kern = cspn3_resident<NQ, NTH, BLEND, MODE, CLEAN, PAC>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -951,9 +970,17 @@ int launch_resident_inst(const ResArgs& a, int grid, size_t lds_bytes, hipStream
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         granted[dev & 63].store(lds_bytes, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RES_THREADS), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds_bytes, st, a);
     HIP_OK(hipGetLastError());
     return 1;
+}
+
+// 1024 threads, one quad per thread: the inference forms only (plain / scored), CSPN_new weights
+template <int CLEAN>
+int launch_resident_1024(const ResArgs& a, int grid, size_t lds, int blend, int mode, hipStream_t st) {
+    if (mode == 0) return blend ? launch_resident_inst<1, 1, 0, CLEAN, 0, 1024>(a, grid, lds, st) : launch_resident_inst<1, 0, 0, CLEAN, 0, 1024>(a, grid, lds, st);
+    if (mode == 1) return blend ? launch_resident_inst<1, 1, 1, CLEAN, 0, 1024>(a, grid, lds, st) : launch_resident_inst<1, 0, 1, CLEAN, 0, 1024>(a, grid, lds, st);
+    return fail("cspn3_forward_resident: 1024-thread workgroups serve the inference forms only");
 }
 
 template <int NQ, int CLEAN>
@@ -994,11 +1021,11 @@ int cspn3_resident_plan(int B, int H, int W, int T, int blend, int n_cu, cspn_re
     if (n_cu <= 0) n_cu = cu_count();
     if (n_cu <= 0) return fail("cspn3_resident_plan: no device (pass n_cu > 0 to plan without one)");
     ResGeom g;
-    if (T < 1 || !resident_geometry(B, H, W, T, blend, n_cu, out->steps_per_phase, &g))
+    if (T < 1 || !resident_geometry(B, H, W, T, blend, n_cu, out->steps_per_phase, &g, out->threads))
         return fail("cspn3_resident_plan: no resident tiling for B=%d %dx%d T=%d on %d CUs (W %% 4 == 0 needed)", B, H, W, T, n_cu);
     if (ceil_div(T, g.S) > 255) return fail("cspn3_resident_plan: T=%d in %d-step phases is more than 255 phases", T, g.S);
     out->steps_per_phase = g.S; out->tiles_x = g.tiles_x; out->tiles_y = g.tiles_y; out->tile_w = g.tw; out->tile_h = g.th;
-    out->quads_per_thread = g.nq; out->threads = RES_THREADS; out->images_per_launch = g.imgs_per_launch;
+    out->quads_per_thread = g.nq; out->threads = g.threads; out->images_per_launch = g.imgs_per_launch;
     out->launches = g.launches; out->lds_bytes = (int)g.lds_bytes; out->n_cu = n_cu;
     out->region_over_tile = (float)((double)(4 * g.wq) * g.wr / ((double)g.tw * g.th));
     return 1;
@@ -1093,16 +1120,19 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         g.S = Se; g.tiles_x = rp.tiles_x; g.tiles_y = rp.tiles_y; g.tw = rp.tile_w; g.th = rp.tile_h;
         g.hyw = Se - 1; g.hxw = round_up4(Se - 1);
         g.wq = (g.tw + 2 * g.hxw) / 4; g.wr = g.th + 2 * g.hyw;
-        g.dr = g.wr + 2; g.ls = 4 * g.wq + 8;
-        g.nq = g.wq > 0 && g.wq <= RES_THREADS ? ceil_div(g.wr, RES_THREADS / g.wq) : RES_MAX_NQ + 1;
-        g.lds_bytes = res_lds_bytes(g.dr, g.ls, g.nq, blend);
+        g.dr = g.wr + 2;
+        g.threads = rp.threads == 1024 ? 1024 : RES_THREADS;
+        g.nq = g.wq > 0 && g.wq <= g.threads ? ceil_div(g.wr, g.threads / g.wq) : RES_MAX_NQ + 1;
+        if (g.threads == 1024 && g.nq > 1) g.nq = RES_MAX_NQ + 1;
+        g.ls = res_row_stride(g.wq, g.nq, g.dr);
+        g.lds_bytes = res_lds_bytes(g.dr, g.ls, g.nq, blend, g.threads);
         g.imgs_per_launch = rp.images_per_launch;
         const int phases = ceil_div(T, Se);
         if ((g.tw & 3) || g.nq > RES_MAX_NQ || g.lds_bytes > 160 * 1024 || (size_t)g.dr * g.ls > (size_t)RES_PP || (phases > 1 && (Se & 1)) || g.tiles_x * g.tw < W || g.tiles_y * g.th < H ||
             (long)g.imgs_per_launch * g.tiles_x * g.tiles_y > ncu ||
             (phases > 1 && ((g.tiles_x > 1 && g.tw < 2 * g.hxw) || (g.tiles_y > 1 && g.th < 2 * g.hyw))))
             return fail("cspn3_forward_resident: the plan does not fit this problem / device (use cspn3_resident_plan)");
-    } else if (!resident_geometry(B, H, W, T, blend, ncu, rp.steps_per_phase, &g)) {
+    } else if (!resident_geometry(B, H, W, T, blend, ncu, rp.steps_per_phase, &g, rp.threads)) {
         return fail("cspn3_forward_resident: no resident tiling for B=%d %dx%d T=%d", B, H, W, T);
     }
     // a tile that finished phase p publishes seq + p + 1, and the next call on the workspace brings seq + 256: more than
@@ -1140,6 +1170,11 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
         const int grid = a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
+        if (g.threads == 1024) {
+            ok = clean ? launch_resident_1024<1>(a, grid, g.lds_bytes, blend, mode, st) : launch_resident_1024<0>(a, grid, g.lds_bytes, blend, mode, st);
+            if (!ok) return 0;
+            continue;
+        }
         switch (g.nq) {
             case 1: ok = launch_resident_nq<1>(a, grid, g.lds_bytes, blend, mode, clean, st); break;
             case 2: ok = launch_resident_nq<2>(a, grid, g.lds_bytes, blend, mode, clean, st); break;

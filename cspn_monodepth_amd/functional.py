@@ -565,10 +565,12 @@ def set_resident(mode):
     _RESIDENT_MODE = mode
 
 
-def resident_plan(B, H, W, T, blend=0, n_cu=0, steps_per_phase=0):
-    """The tiling cspn3_forward_resident would use (dict), or None when the shape has none (W % 4 != 0, T < 1, ...)."""
+def resident_plan(B, H, W, T, blend=0, n_cu=0, steps_per_phase=0, threads=0):
+    """The tiling cspn3_forward_resident would use (dict), or None when the shape has none (W % 4 != 0, T < 1, ...).
+    threads: 0 / 512 = the 512-thread workgroups, 1024 = one quad per thread on 1024 threads (inference forms only)."""
     rp = _lib.cspn_resident_plan()
     rp.steps_per_phase = int(steps_per_phase)
+    rp.threads = int(threads)
     ok = _lib.lib().cspn3_resident_plan(int(B), int(H), int(W), int(T), int(blend), int(n_cu), ctypes.byref(rp))
     if not ok:
         return None
@@ -633,11 +635,12 @@ class _JournalEntry(object):
     inputs the caller has since overwritten in place would silently produce the result of ANOTHER batch."""
     __slots__ = ("redo", "out", "inputs", "versions", "nbytes", "what")
 
-    def __init__(self, redo, out=None, inputs=(), what="resident launch"):
+    def __init__(self, redo, out=None, inputs=(), what="resident launch", nbytes=None):
         self.redo, self.out, self.what = redo, out, what
         self.inputs = tuple(t for t in inputs if t is not None)
         self.versions = tuple(t._version for t in self.inputs)
-        self.nbytes = sum(t.numel() * t.element_size() for t in self.inputs) + (0 if out is None else out.numel() * out.element_size())
+        self.nbytes = nbytes if nbytes is not None else (
+            sum(t.numel() * t.element_size() for t in self.inputs) + (0 if out is None else out.numel() * out.element_size()))
 
     def inputs_untouched(self):
         return all(t._version == v for t, v in zip(self.inputs, self.versions))
@@ -1077,7 +1080,7 @@ def pac_transposed_resident(wk, g_T, sparse, T):
 
 
 def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, steps_per_phase=0, spin_limit=0, debug_stamps=None,
-                     keep_history=False, publish_weights=True, guard=None, _plan=None):
+                     keep_history=False, publish_weights=True, guard=None, _plan=None, threads=0):
     """Refined depth [B,H,W] by the weight-resident launch; `score=(target, acc)` fuses the depth metrics into it.
 
     keep_history=True is the training forward: returns (d_T [view of history[T-1]], history [T,B,H,W], w8 [B,8,H,W],
@@ -1100,9 +1103,10 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
     guard = int(_RESIDENT_GUARD and score is None and int(T) <= _GUARD_MAX_T) if guard is None else int(guard)
     if _plan is not None and not _RESIDENT_SPIN_LIMIT:
         rp = _plan                                     # the caller's cached (guarded) plan: CSPN3Function's fast path
-    elif steps_per_phase or spin_limit or debug_stamps is not None:
+    elif steps_per_phase or spin_limit or debug_stamps is not None or threads:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
+        rp.threads = int(threads)
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
         rp.guard = guard
@@ -1629,7 +1633,62 @@ class PACFunction(torch.autograd.Function):
         return gx, gg, None, None, None, None, None
 
 
-_SCORED_FAST = {}      # call signature -> True: cspn3_refine_and_score goes straight to the scored resident launch
+_SCORED_FAST = {}      # call signature -> _ScoredFast: cspn3_refine_and_score goes straight to the scored resident launch
+
+
+class _ScoredFast(object):
+    """Everything a scored resident forward of one call signature needs, resolved once (round 5: at per-GPU shard sizes the call is
+    HOST-bound — 20 us of host time against 17 us of kernel, tools/probes/r05_shard_host.py): the cached plan, the device's
+    state, the workspace, the constant arguments of the C call.  `issue` is _resident_launch + forward_resident with nothing left
+    to look up; whatever it does not handle (another device current, a stream change, HIP-graph capture, an event log, a sequence
+    wrap, an evicted workspace) returns None and the caller takes the general path."""
+    __slots__ = ("plan", "dev", "idx", "st", "work", "wkey", "B", "H", "W", "T", "blend", "gs0", "gs1", "nslots", "nbytes", "what", "cfunc")
+
+    def __init__(self, plan, guidance, T, blend, acc):
+        B, C, H, W = guidance.shape
+        self.plan, self.dev, self.idx = plan, guidance.device, guidance.device.index
+        self.st = _resident_state(guidance.device)
+        self.wkey = (B, H, W, "3", 4)
+        self.work = self.st["work"].get(self.wkey)
+        self.B, self.H, self.W, self.T, self.blend = B, H, W, int(T), int(blend)
+        self.gs0, self.gs1, self.nslots = guidance.stride(0), guidance.stride(1), int(acc.shape[0])
+        self.nbytes = (guidance.numel() + (3 + int(bool(blend))) * B * H * W) * 4
+        self.what = "cspn3_forward_resident %dx%dx%d (scored)" % (B, H, W)
+        self.cfunc = _lib.lib().cspn3_forward_resident
+
+    def issue(self, guidance, d0, sparse, target, acc):
+        st = self.st
+        if (_EVENT_LOG is not None or _RESIDENT_SPIN_LIMIT or self.work is None or st["work"].get(self.wkey) is not self.work
+                or torch._C._cuda_getDevice() != self.idx or torch._C._cuda_isCurrentStreamCapturing()):
+            return None
+        raw = torch._C._cuda_getCurrentRawStream(self.idx)
+        if raw != st.get("last_raw") or st["seq"] > _RES_SEQ_MAX:
+            return None
+        out = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
+        B, H, W, T, blend = self.B, self.H, self.W, self.T, self.blend
+        with st["lock"]:
+            if st["host_err_np"][0] != 0:
+                _recover(self.dev, st)
+            seq = st["seq"]
+            st["seq"] = seq + _RES_SEQ_STEP
+            ok = self.cfunc(guidance.data_ptr(), self.gs0, self.gs1, d0.data_ptr(), None if sparse is None else sparse.data_ptr(), out.data_ptr(),
+                            None, None, None, self.work.data_ptr(), seq, st["host_err_ptr"], B, H, W, 0, T, blend, target.data_ptr(),
+                            acc.data_ptr(), self.nslots, self.plan, raw)
+            if ok:
+                st["dirty"] = True
+                st["last_reports"] = False
+
+                def redo():        # the same call on the multi-launch schedule, into the same tensors (bit-identical: DESIGN.md §4.1b)
+                    from . import evaluation
+                    tgp = target.reshape(B, H, W)
+                    _unscore_failed_launch(out, tgp, acc)
+                    res, _ = propagate_from_guidance(guidance, d0.reshape(B, H, W), None if sparse is None else sparse.reshape(B, H, W), T, blend)
+                    out.copy_(res)
+                    evaluation.metric_sums(out, tgp, out=acc)
+
+                _journal_add(self.dev, st, _JournalEntry(redo, out, (guidance, d0, sparse, target), self.what, self.nbytes), st["last_stream"])
+        _lib.check(ok, "cspn3_forward_resident")
+        return out
 
 
 def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop_time=24, plan=None):
@@ -1652,9 +1711,12 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
                 and not ((guidance.data_ptr() | blur_depth.data_ptr() | target.data_ptr() |
                           (0 if sparse_depth is None else sparse_depth.data_ptr())) & 15)
                 and blur_depth.device == target.device == guidance.device and (sparse_depth is None or sparse_depth.device == guidance.device)):
-            with torch.no_grad():
-                return forward_resident(guidance, blur_depth, sparse_depth, prop_time, BLEND_NONE if sparse_depth is None else BLEND_SPARSE,
-                                        score=(target, acc), guard=0, _plan=fast_plan).unsqueeze(1)
+            out = fast_plan.issue(guidance, blur_depth, sparse_depth, target, acc)
+            if out is None:        # something the lean path does not handle (stream change, capture, ...): the general one
+                with torch.no_grad():
+                    out = forward_resident(guidance, blur_depth, sparse_depth, prop_time, fast_plan.blend, score=(target, acc), guard=0,
+                                           _plan=fast_plan.plan)
+            return out.unsqueeze(1)
     dev = _require_device(guidance, blur_depth, sparse_depth, target)
     W0 = guidance.shape[-1]
     pad = _row_padding(W0, plan)
@@ -1673,7 +1735,8 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
             if key is not None and not pad and blur_depth.dim() == 4 and target.dim() == 4 and (sparse_depth is None or sparse_depth.dim() == 4):
                 if len(_SCORED_FAST) > 256:
                     _SCORED_FAST.clear()
-                _SCORED_FAST[key] = _resident_plan_cached(B, H, W, int(prop_time), int(blend), guidance.device)[1]
+                _SCORED_FAST[key] = _ScoredFast(_resident_plan_cached(B, H, W, int(prop_time), int(blend), guidance.device)[1], guidance,
+                                                prop_time, blend, acc)
             return out.unsqueeze(1)[..., :W0]
         if (_FROM_GUIDANCE and from_guidance_supported(guidance, d0, sp, plan) and guidance.dtype == d0.dtype
                 and tg.dtype == d0.dtype and tg.data_ptr() % 16 == 0):

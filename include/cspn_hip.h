@@ -272,7 +272,8 @@ typedef struct cspn_resident_plan {
                            /* than one phase (an odd request then has no plan); any value <= T otherwise   */
     int tiles_x, tiles_y;  /* tiles per image                                                             */
     int tile_w, tile_h;
-    int quads_per_thread, threads;
+    int quads_per_thread, threads;   /* threads, cspn3_*: in 0 / 512 = 512-thread workgroups (all forms), 1024 = one quad per thread on 1024
+                                      * threads, four wavefronts per SIMD (inference forms only; small shards, round 5); out: the value used */
     int images_per_launch, launches;
     int lds_bytes, n_cu;
     float region_over_tile; /* (tile + halo) area / tile area: the redundant-compute factor of the phases  */

@@ -644,15 +644,20 @@ def test_timeout_in_a_training_step_raises_before_backward_returns(where, c_orac
         for broken in (True, False):
             g_ = gt.clone().requires_grad_(True)
             d_ = dt.clone().requires_grad_(True)
-            with spin_limit(1 if (broken and where == "forward") else 0):
-                out = m(g_, d_, None)
-            loss = (out * out).mean()
+
+            def step():
+                with spin_limit(1 if (broken and where == "forward") else 0):
+                    out = m(g_, d_, None)
+                loss = (out * out).mean()
+                with spin_limit(1 if (broken and where == "reverse_sweep") else 0):
+                    loss.backward()
             if broken:
+                # (raised by the end-of-backward check at the latest; a host that looks at the error word earlier — the launch
+                #  protocol does after every launch — may raise from the forward call already)
                 with pytest.raises(RuntimeError, match="timed out waiting for a neighbouring tile"):
-                    with spin_limit(1 if where == "reverse_sweep" else 0):
-                        loss.backward()
+                    step()
             else:
-                loss.backward()                                         # the path works again
+                step()                                                  # the path works again
                 torch.cuda.synchronize()
                 assert bool(torch.isfinite(g_.grad).all()) and bool(torch.isfinite(d_.grad).all())
     torch.cuda.synchronize()

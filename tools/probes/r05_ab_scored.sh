@@ -1,6 +1,5 @@
 #!/bin/bash
-# same-box A/B (round 5): border-only publish of the resident exchange (lib_border) against publishing the whole interior
-# (lib_puball = -DCSPN_RES_PUBLISH_ALL=1), scored forwards at config 2 / its sparse form / KITTI B=8 / the shards; three rounds interleaved
+# same-box A/B of library variants under _ab/ (CSPN_HIP_LIB) on the scored forwards: config 2 / sparse / KITTI B=8 / shards; three rounds interleaved
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for r in 1 2 3; do for v in "$@"; do
 CSPN_HIP_LIB=$PWD/_ab/lib_$v.so python - <<PY
