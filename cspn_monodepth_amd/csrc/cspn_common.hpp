@@ -39,7 +39,8 @@ int pac_s2_grad_kernel(const void* gout, const void* in, void* gk, int dtype, in
 bool resident_repair_fits(int T);
 int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, float* hist, float* s_out,
                            float* w_out, const float* s_in, int mode, const unsigned* abort_word, unsigned seq, int B, int H, int W, int Wv,
-                           int T, int blend, int n_cu, void* stream);      // mode 0: inference, 2: training forward, 4: volume-free reverse sweep
+                           int T, int blend, int n_cu, void* stream);      // mode 0: inference, 2: training forward, 3 / 4: reverse sweep from a tap volume / from
+                                                                                 // guidance + S, 10 / 12: softmax-weight (CSPN_ours K = 3) inference / training forward
 // cspn_debug.hip: the poisoned-LDS debugging aid (include/cspn_hip.h: cspn_debug_set_lds_poison)
 extern int g_lds_poison_on;
 void lds_poison(hipStream_t st);

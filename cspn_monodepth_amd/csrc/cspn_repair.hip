@@ -39,11 +39,15 @@ __device__ __forceinline__ float rcp_as_forward(float S) {
 
 // MODE 0: inference (refined depth -> out).  MODE 2: the training forward — every step's state goes to its history plane, the
 // normaliser S (and, when asked for, the taps) is published.  MODE 4: the volume-free reverse sweep G_t = stencil^T((1-m) G_{t+1}) on
-// the taps |g_j[p]| / S[p + off_j]; d0 is G_T, the history receives G_{T-1} .. G_0, (1-m) G travels.
-template <int BLEND, int MODE>
+// the taps |g_j[p]| / S[p + off_j]; d0 is G_T, the history receives G_{T-1} .. G_0, (1-m) G travels.  MODE 3: the same sweep on taps
+// gathered from a forward tap volume (a.g = [B,8,H,W]): tap j = w_{7-j}[p + off_j].
+// PAC = 1 (MODE 0 / 2): the K = 3 softmax form of CSPN_ours.py:35-41 — tap j = softmax over the 8 guidance channels at the pixel
+// itself, with the arithmetic of cspn3_resident's PAC instances (maximum, two-piece exponential, sum in channel order, one refined
+// reciprocal); MODE 2 publishes the taps (no S).
+template <int BLEND, int MODE, int PAC>
 __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepArgs a) {
     if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) return;      // the call finished: nothing to do
-    constexpr bool TRANS = MODE == 4, HIST = MODE != 0;
+    constexpr bool TRANSG = MODE == 4, TRANS = MODE == 3 || MODE == 4, HIST = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int T = a.T, R = REP_TILE + 2 * T, H = a.H, W = a.W, Wv = a.Wv;
     float* cur = lds;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
         const float* __restrict__ gb = a.g + (size_t)b * a.g_bs;
         const float* __restrict__ db = a.d0 + b * HW;
         const float* __restrict__ sb = BLEND ? a.sparse + b * HW : nullptr;
-        const float* __restrict__ sib = TRANS ? a.s_in + b * HW : nullptr;
+        const float* __restrict__ sib = TRANSG ? a.s_in + b * HW : nullptr;
         __syncthreads();                                                   // (the previous tile's readers are done)
         for (int i = threadIdx.x; i < R * R; i += REP_THREADS) {
             const int ry = i / R, rx = i - ry * R, y = ry0 + ry, x = rx0 + rx;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
                     float qv[8];
                     float m = 0.f;
                     if (BLEND) m = sgnf(sb[(size_t)y * W + x]);
-                    if (TRANS) {
+                    if (TRANSG) {
                         // tap j = |channel j at p| x 1 / S[p + off_j] (the forward's refined reciprocal), 0 where p + off_j is outside
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -87,6 +91,32 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
                             const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < Wv;
                             const float rs = ok ? rcp_as_forward(sib[(size_t)yy * W + xx]) : 0.f;
                             qv[j] = fabsf(gb[(size_t)j * a.g_cs + (size_t)y * W + x]) * rs;
+                        }
+                    } else if (TRANS) {
+                        // tap j = w_{7-j}[p + off_j] from the forward's tap volume, 0 outside the image
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int lin = j < 4 ? j : j + 1, yy = y + lin / 3 - 1, xx = x + lin % 3 - 1;
+                            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                            qv[j] = ok ? gb[(size_t)(7 - j) * a.g_cs + (size_t)yy * W + xx] : 0.f;
+                        }
+                    } else if (PAC) {
+                        float mx = -INFINITY, den = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { qv[j] = gb[(size_t)j * a.g_cs + (size_t)y * W + x]; mx = fmaxf(mx, qv[j]); }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { qv[j] = softmax_exp<float>(qv[j] - mx); den += qv[j]; }
+                        const float inv = reciprocal_refined(den);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) qv[j] = softmax_weight<float>(qv[j], inv);
+                        if (MODE == 2 && mine && s == 1) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) a.w_out[((size_t)b * 8 + j) * HW + (size_t)y * W + x] = qv[j];
+                        }
+                        if (BLEND) {
+                            const float om = 1.f - m;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) qv[j] *= om;
                         }
                     } else {
                         // taps as cspn3_resident derives them: tap j (row-major without the centre) = |channel 7-j| at p + off_j, 0
@@ -130,7 +160,7 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
                     }
                     if (HIST && mine) hp[(size_t)y * W + x] = u;
                 }
-                else if (MODE == 2 && s == 1 && y >= 0 && y < H && x >= Wv && x < W && (x & ~3) < Wv && ry >= T && ry < T + REP_TILE && rx >= T && rx < T + REP_TILE) {
+                else if (MODE == 2 && !PAC && s == 1 && y >= 0 && y < H && x >= Wv && x < W && (x & ~3) < Wv && ry >= T && ry < T + REP_TILE && rx >= T && rx < T + REP_TILE) {
                     // row padding inside the last valid quad: the resident launch stores that quad's S (and zero taps) as a whole
                     float S = 0.f;
 #pragma unroll
@@ -171,21 +201,29 @@ int resident_repair_launch(const float* g, long bs, long cs, const float* d0, co
                            float* w_out, const float* s_in, int mode, const unsigned* abort_word, unsigned seq, int B, int H, int W, int Wv,
                            int T, int blend, int n_cu, void* stream) {
     if (!resident_repair_fits(T)) return fail("cspn3_forward_resident: the guard re-computes at most 54 steps (T=%d)", T);
-    if (mode != 0 && mode != 2 && mode != 4) return fail("cspn3_forward_resident: the guard has no form for this launch");
+    if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 10 && mode != 12) return fail("cspn3_forward_resident: the guard has no form for this launch");
     RepArgs a{g, bs, cs, d0, sparse, out, hist, s_out, w_out, s_in, abort_word, seq, B, H, W, Wv, T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
     const size_t lds = (size_t)2 * (REP_TILE + 2 * T) * (REP_TILE + 2 * T) * sizeof(float);
-    static std::atomic<size_t> granted[6][64];
+    static std::atomic<size_t> granted[12][64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
-    const int slot = (mode == 0 ? 0 : mode == 2 ? 2 : 4) + (blend ? 1 : 0);
+    // slots: (inference, training forward, sweep from guidance + S, sweep from a tap volume, softmax inference, softmax training forward) x blend
+    const int form = mode == 0 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : mode == 3 ? 3 : mode == 10 ? 4 : 5;
+    const int slot = 2 * form + (blend ? 1 : 0);
     void (*kern)(RepArgs) = nullptr;
     switch (slot) {
-        case 0: kern = cspn3_resident_repair<0, 0>; break;
-        case 1: kern = cspn3_resident_repair<1, 0>; break;
-        case 2: kern = cspn3_resident_repair<0, 2>; break;
-        case 3: kern = cspn3_resident_repair<1, 2>; break;
-        case 4: kern = cspn3_resident_repair<0, 4>; break;
-        default: kern = cspn3_resident_repair<1, 4>; break;
+        case 0: kern = cspn3_resident_repair<0, 0, 0>; break;
+        case 1: kern = cspn3_resident_repair<1, 0, 0>; break;
+        case 2: kern = cspn3_resident_repair<0, 2, 0>; break;
+        case 3: kern = cspn3_resident_repair<1, 2, 0>; break;
+        case 4: kern = cspn3_resident_repair<0, 4, 0>; break;
+        case 5: kern = cspn3_resident_repair<1, 4, 0>; break;
+        case 6: kern = cspn3_resident_repair<0, 3, 0>; break;
+        case 7: kern = cspn3_resident_repair<1, 3, 0>; break;
+        case 8: kern = cspn3_resident_repair<0, 0, 1>; break;
+        case 9: kern = cspn3_resident_repair<1, 0, 1>; break;
+        case 10: kern = cspn3_resident_repair<0, 2, 1>; break;
+        default: kern = cspn3_resident_repair<1, 2, 1>; break;
     }
     if (lds > 64 * 1024 && granted[slot][dev & 63].load(std::memory_order_acquire) < lds) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1162,8 +1162,10 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     a.dbg = rp.debug_stamps;
     const bool clean = regions_inside_image(g, H, W, a.Wv, T);
     // (refused rather than ignored: a host that asked for the guard relies on `out` being complete for GPU-side consumers)
-    if (rp.guard && ((mode != 0 && mode != 2 && mode != 7) || (mode == 0 && !out) || !cspn_detail::resident_repair_fits(T)))
-        return fail("cspn3_forward_resident: plan->guard serves the unscored CSPN_new forms (inference, training forward, volume-free reverse sweep) of T <= 54 steps");
+    // mode: 0 / 1 / 2 inference / scored / training forward, 3 / 7 reverse sweep from a tap volume / from guidance + S, 4 / 5 / 6 the softmax forms
+    if (rp.guard && ((mode != 0 && mode != 2 && mode != 3 && mode != 7 && mode != 4 && mode != 6) || ((mode == 0 || mode == 4) && !out) ||
+                     !cspn_detail::resident_repair_fits(T)))
+        return fail("cspn3_forward_resident: plan->guard serves the unscored forms (inference, training forward, reverse sweeps) of T <= 54 steps");
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
@@ -1186,8 +1188,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
         if (!ok) return 0;
     }
     if (rp.guard)
-        return cspn_detail::resident_repair_launch(a.g, bs, cs, a.d0, a.sparse, a.out, a.hist, a.s_out, a.w_out, a.s_in, mode == 7 ? 4 : mode, a.status, seq,
-                                                   B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st);
+        return cspn_detail::resident_repair_launch(a.g, bs, cs, a.d0, a.sparse, a.out, a.hist, a.s_out, a.w_out, a.s_in,
+                                                   mode == 7 ? 4 : mode == 4 ? 10 : mode == 6 ? 12 : mode, a.status, seq, B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st);
     return 1;
 }
 

@@ -848,6 +848,7 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         return cspn_detail::resident_pac3_f32(guided, x0, sparse, out, nullptr, nullptr, work, seq, host_err, B, H, W, T, blend, target, acc,
                                               nslots, &qp, stream);
     }
+    if (rp.guard) return fail("cspnk_forward_resident: plan->guard exists for K = 3 with fp32 guidance only (the oct kernels have no re-computation form)");
     if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
         const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
         if (!kgeom_fill(K, g_dtype, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
@@ -911,6 +912,7 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
 int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_T, const void* sparse_f32, int in_dtype, float* g_T_f32_out,
                               float* history, void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int premask,
                               const cspn_resident_plan* plan, cspn_stream_t stream) {
+    if (plan && plan->guard) return fail("cspnk_transposed_resident: no guard form (the K = 3 fp32 model's sweep is cspn3_transposed_resident)");
     if (!wk || !g_T || !history || !work || B <= 0 || H <= 0 || W <= 0 || T < 1) return fail("cspnk_transposed_resident: bad arguments");
     if (K != 5 || w_dtype != CSPN_F16) return fail("cspnk_transposed_resident: K = 5 with an fp16 tap volume (K=%d, dtype %d)", K, w_dtype);
     if (premask && !sparse_f32) return fail("cspnk_transposed_resident: premask needs sparse");
@@ -974,6 +976,8 @@ int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_
 int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const void* x0, const void* sparse, void* history, void* wk_out,
                                    void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend,
                                    const cspn_resident_plan* plan, cspn_stream_t stream) {
+    if (plan && plan->guard && !(K == 3 && g_dtype == CSPN_F32))
+        return fail("cspnk_forward_resident_history: plan->guard exists for K = 3 with fp32 guidance only");
     if (!guided || !x0 || !history || !wk_out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1)
         return fail("cspnk_forward_resident_history: bad arguments");
     if (K == 5 && g_dtype == CSPN_F16) {

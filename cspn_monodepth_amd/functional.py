@@ -1017,14 +1017,15 @@ def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
     B, H, W = g_T.shape
     L = _lib.lib()
     ghist = torch.empty((int(T), B, H, W), dtype=torch.float32, device=dev)
-    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1])
+    guard = int(_RESIDENT_GUARD and int(T) <= _GUARD_MAX_T)
+    rp = _with_spin_limit(_resident_plan_cached(B, H, W, int(T), int(sparse_f32 is not None), dev)[1], guard=guard)
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspn3_transposed_resident(_p(w8), _p(g_T), _p(sparse_f32), _p(ghist), _p(work), seq, host_err_ptr, B, H, W,
                                            int(valid_w), int(T), int(sparse_f32 is not None),
                                            None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True, guarded=bool(guard))
     _lib.check(ok, "cspn3_transposed_resident")
     return ghist
 
@@ -1223,6 +1224,9 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
     form = _KRES_STEP_FORM if step_form is None else int(step_form)
     if form == _lib.STEP_DOT2 and not (K == 5 and guided.dtype == torch.float16 and x0.dtype == torch.float16):
         form = _lib.STEP_AUTO                      # a process-wide "dot2" only pins the calls that have the kernel
+    # the K = 3 / fp32-guidance model (what the reference's unet_ours runs) is served by the quad kernel, which has the device-side
+    # guard (csrc/cspn_repair.hip: softmax forms); the oct kernels (fp16 guidance, K = 5) keep the host repair
+    guard = int(_RESIDENT_GUARD and score is None and K == 3 and guided.dtype == torch.float32 and int(T) <= _GUARD_MAX_T)
     if steps_per_phase or spin_limit or debug_stamps is not None or threads:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
@@ -1230,8 +1234,9 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
         rp.spin_limit = int(spin_limit)
         rp.debug_stamps = None if debug_stamps is None else debug_stamps.data_ptr()
         rp.step_form = form
+        rp.guard = guard
     else:
-        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, _dt(guided))[1], form)
+        rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, _dt(guided))[1], form, guard)
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspnk_forward_resident(_p(guided), _dt(guided), K, _p(x0), _p(sparse), _p(out), sdt, _p(work), seq, host_err_ptr, B, H, W,
@@ -1250,7 +1255,7 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
 
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
                           ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), redo=redo, out=out,
-                          inputs=(guided, x0, sparse, tg), what="cspnk_forward_resident %dx%dx%d" % (B, H, W))
+                          inputs=(guided, x0, sparse, tg), what="cspnk_forward_resident %dx%dx%d" % (B, H, W), guarded=bool(guard))
     _lib.check(ok, "cspnk_forward_resident")
     return out
 
@@ -1268,7 +1273,8 @@ def pac_forward_resident_history(guided, x0, sparse, T):
     wk = _weight_buffer(B, C, H, W, guided.dtype, dev)
     blend = BLEND_SPARSE if sparse is not None else BLEND_NONE
     gdt = _dt(guided)
-    rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, gdt)[1])
+    guard = int(_RESIDENT_GUARD and K == 3 and guided.dtype == torch.float32 and int(T) <= _GUARD_MAX_T)
+    rp = _with_spin_limit(_kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, gdt)[1], guard=guard)
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspnk_forward_resident_history(_p(guided), gdt, K, _p(x0), _p(sparse), _p(hist), _p(wk), _p(work), seq, host_err_ptr,
@@ -1276,7 +1282,7 @@ def pac_forward_resident_history(guided, x0, sparse, T):
 
     sdt = _dt(x0)
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
-                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), reports_done=True)
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), reports_done=True, guarded=bool(guard))
     _lib.check(ok, "cspnk_forward_resident_history")
     return hist[int(T) - 1], hist, wk
 

@@ -374,6 +374,66 @@ def test_k3_fp32_training_forward_publishes_what_the_backward_needs(B, H, W, T, 
     assert np.allclose(grads["on"][1], grads["off"][1], rtol=0, atol=1e-6 * float(np.abs(wg).max()))
 
 
+class _spin_limit(object):
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = F._RESIDENT_SPIN_LIMIT
+        F._RESIDENT_SPIN_LIMIT = self.n
+
+    def __exit__(self, *exc):
+        F._RESIDENT_SPIN_LIMIT = self.prev
+        return False
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 228, 304, 24), (1, 352, 1216, 24), (2, 37, 40, 7), (5, 60, 64, 9)], ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_unet_ours_configuration_is_guarded_on_the_device(B, H, W, T, sparse, c_oracle):
+    """Round 5: the model the reference's get_model returns (unet_ours: CSPN_ours.AffinityPropagate(24) on an 8-channel fp32
+    guidance, network/unet_ours.py:305, :333) is served by the quad kernel in its softmax-weight form, and that form carries the
+    device-side guard (csrc/cspn_repair.hip) for inference, for the training forward and for the reverse sweep on the published
+    tap volume.  Every tile is forced to give up (one poll): the refined depth is the multi-launch schedule's bits for a GPU
+    consumer enqueued right behind the call, and a training step neither raises nor changes a bit of its gradients."""
+    import warnings
+    K = 3
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=120)
+    xt, gt, st = dev(x), dev(gd), dev(s)
+    m = pkg.CSPN_ours.AffinityPropagate(T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with torch.no_grad(), resident("on"):
+            rp = F.pac_resident_supported(gt, xt[:, 0].contiguous(), None if st is None else st[:, 0].contiguous(), T)
+            assert rp is not None
+            ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], None)
+            with _spin_limit(1):
+                out = m(xt, gt, sparse_depth=st)
+            total = out.double().sum()                  # a GPU consumer this package knows nothing about
+            assert float(total) == float(ref.double().sum()) and bits_equal(out, ref, which="softmax form, guard-repaired")
+            F.ensure_resident_ok()
+        if B * H * W > 3 * 228 * 304:
+            return
+        cot = dev(c_oracle.hash_normal(121, 9, (B, 1, H, W)))
+
+        def step(lf, lb):
+            xg, gg = dev(x).requires_grad_(True), dev(gd).requires_grad_(True)
+            with _spin_limit(lf):
+                o = m(xg, gg, sparse_depth=st)
+            with _spin_limit(lb):
+                o.backward(cot)
+            return o.detach(), xg.grad, gg.grad
+
+        with resident("on"):
+            want = step(0, 0)
+            torch.cuda.synchronize()
+            for lf, lb in ((1, 0), (0, 1), (1, 1)):
+                got = step(lf, lb)
+                for a, b_, what in zip(got, want, ("refined depth", "dL/dx", "dL/dguided")):
+                    assert bits_equal(a, b_, which="%s, time-out forced in %s" % (what, "forward" if lf else "sweep"))
+            F.ensure_resident_ok()
+    F.check_resident_errors()
+
+
 D2_SHAPES = [(24, 228, 304, 12, 4), (3, 228, 304, 12, 4), (1, 352, 1216, 12, 4), (2, 40, 64, 12, 4), (2, 13, 24, 5, 5), (5, 60, 72, 7, 2),
              (1, 9, 8, 3, 2), (30, 120, 160, 9, 4), (25, 228, 304, 12, 4), (2, 48, 64, 12, 6)]
 
