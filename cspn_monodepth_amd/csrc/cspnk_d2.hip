@@ -89,9 +89,6 @@ __device__ __forceinline__ void softmax_to_pairs(const unsigned (&w)[24], float 
 }
 
 constexpr int D2_R = 2, D2_NT = 24;
-#ifndef CSPN_D2_STAGGER
-#define CSPN_D2_STAGGER 0
-#endif
 
 // MODE 0: inference; 1: inference + fused depth metrics; 2: the training forward — every step's state goes to its fp16 history
 // plane and the softmax taps are published once as the fp16 tap volume (pairs (2i, 2i+1) interleaved per quad: cspn_common.hpp
@@ -204,26 +201,6 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
             rg[k] = IO::ld_pair(x0b, in ? (unsigned)(y * W + x) : 0u);
         }
 
-        // ---- staggered start (round 5 experiment, -DCSPN_D2_STAGGER=G): the guidance stream of a round is HBM-bound (67 MB in ~11 us for
-        // 240 workgroups) while the phases that follow it are not, and a launch runs two rounds: with the images of a launch split into G
-        // groups that enter their FIRST stream one after the other (group g waits until the tile of the same index of group g - 1 has its
-        // taps), every later stream of a group falls into the others' step phases and has the memory system to itself.
-#if CSPN_D2_STAGGER > 1
-        {
-            const int per = (a.nb + CSPN_D2_STAGGER - 1) / CSPN_D2_STAGGER;      // images per group
-            if (round == 0 && bl >= per) {
-                if (tid == 0) {
-                    const unsigned* f = a.flags + (size_t)(b - per) * tiles_per_img + trem;
-                    unsigned spins = 0;
-                    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.seq) < 0) {
-                        if (++spins > (1u << 16)) break;               // (an experiment: no abort protocol — never wait for long)
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-#endif
         // ---- 1. guidance of the owned oct: 24 16-byte loads, all requested before the arithmetic ----------------------
         uint4 graw[NT];
         const __half* __restrict__ gb = kuniform_ptr(static_cast<const __half*>(a.g) + (size_t)b * NT * HW);
@@ -324,10 +301,6 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
             }
         }
         stamp();                                              // weights derived
-#if CSPN_D2_STAGGER > 1
-        if (round == 0 && tid == 0)                           // this tile's first stream is over: the next group's tile of this index may start
-            __hip_atomic_store(a.flags + (size_t)b * tiles_per_img + trem, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 
         // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes --------------------
         __half* __restrict__ outb = HIST ? nullptr : kuniform_ptr(static_cast<__half*>(a.out) + (size_t)b * HW);

@@ -59,9 +59,15 @@ def use_tuned_conv_db(rank=0, force=False):
 
     The copy lives under the user's cache directory ($XDG_CACHE_HOME or ~/.cache, created 0700 — NOT a predictable name in the
     world-writable temp dir, where another local user could pre-create the directory or plant symlinks: ADVICE r3), in a
-    directory per (rank, job): the job id comes from TORCHELASTIC_RUN_ID / SLURM_JOB_ID when there is one, so the ranks of a
-    job restart onto the database they extended and two jobs of one user never share live files.  Files are installed only when
-    missing (exclusive create + rename; existing files — what MIOpen appended on earlier runs — are kept)."""
+    directory per rank — `miopen_db_rank<r>`: a plain `python train.py` finds on its next run what MIOpen learned on this one
+    (a per-pid name made a new directory every run and never reused one) — and, when a scheduler names the job
+    (SLURM_JOB_ID, or a TORCHELASTIC_RUN_ID other than torchrun's default literal "none"), per job as well, so that the ranks of a
+    job restart onto the database they extended and two named jobs of one user never share live files.  Concurrent UNNAMED runs
+    of one user on one machine share the per-rank files; MIOpen appends whole lines, and CSPN_MIOPEN_DB_TAG gives a run its own
+    directory.  Files are installed only when missing (exclusive create + rename; existing files — what MIOpen appended on
+    earlier runs — are kept).  Per-pid directories of earlier versions and the random-name fallbacks of this one are not created
+    any more (the fallback, used only when no private cache directory can be had, lives under the temp dir and is removed at
+    interpreter exit)."""
     if os.environ.get("MIOPEN_USER_DB_PATH") and not force:
         return None
     files = [f for f in os.listdir(DB_DIR) if f.endswith(".txt")] if os.path.isdir(DB_DIR) else []
@@ -72,10 +78,14 @@ def use_tuned_conv_db(rank=0, force=False):
         os.makedirs(cache, mode=0o700, exist_ok=True)
         base = _private_dir(os.path.join(cache, "cspn_monodepth_amd"))
     except (OSError, RuntimeError):
-        base = tempfile.mkdtemp(prefix="cspn_miopen_db_")            # no usable home: a fresh 0700 directory with a random name
-    job = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or "pid%d" % os.getpid()
+        base = tempfile.mkdtemp(prefix="cspn_miopen_db_")            # no usable home: a fresh 0700 directory with a random name,
+        import atexit                                                 # gone with the process (nothing to reuse it by)
+        atexit.register(shutil.rmtree, base, True)
+    job = os.environ.get("CSPN_MIOPEN_DB_TAG") or os.environ.get("SLURM_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    if job == "none":                                                 # torchrun's default run id: not a name
+        job = ""
     job = "".join(c if c.isalnum() or c in "-_." else "_" for c in job)[:64]
-    dst = _private_dir(os.path.join(base, "miopen_db_%s_rank%d" % (job, int(rank))))
+    dst = _private_dir(os.path.join(base, "miopen_db_%srank%d" % (job + "_" if job else "", int(rank))))
     for f in files:
         _install(os.path.join(DB_DIR, f), os.path.join(dst, f))
     os.environ["MIOPEN_USER_DB_PATH"] = dst

@@ -197,8 +197,10 @@ int cspn_pac_grad_guided(const void* wk, int w_dtype, const float* gw, void* gra
  *   cspn3_backward_tail    = cspn_grad_weights + cspn3_grad_guidance   (all tensors of one dtype)
  *   cspn_pac_backward_tail = cspn_grad_weights + cspn_pac_grad_guided
  * cspn3_backward_tail does not read the tap volume (ABI 9): w_j[p] = |g_{7-j}[p + off_j]| / S[p] is rebuilt from the guidance
- * quads its epilogue loads anyway and from s, by the forward's recipe (bit-identical fp32 taps); w8_or_null is accepted for
- * source compatibility and ignored. */
+ * quads its epilogue loads anyway and from s, by the forward's recipe — |g| x (v_rcp_f32(S) + one Newton step): the fp32 taps are the
+ * forward's bits for every normaliser in [2^-100, 2^100]; outside that range the forward takes true divisions (cspn_common.hpp:
+ * div8_shared_reciprocal) and the rebuilt taps may differ from them in the last bit.  w8_or_null is accepted for source
+ * compatibility and ignored. */
 int cspn3_backward_tail(const void* d0, const void* dhist, const float* g_T, const float* ghist, const void* sparse,
                         const void* guidance, long g_batch_stride, long g_chan_stride, int C, const void* w8_or_null,
                         const float* s, void* grad_guidance, float* gd0, int dtype, int B, int H, int W, int T,

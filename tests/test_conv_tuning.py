@@ -26,6 +26,22 @@ def test_use_tuned_conv_db_copies_per_rank_and_respects_the_environment(monkeypa
     assert d1 and d1 != d0 and os.environ["MIOPEN_USER_DB_PATH"] == d1
 
 
+def test_database_directory_is_stable_across_runs_of_an_unnamed_job(monkeypatch, tmp_path):
+    """without a scheduler's job id the directory must not be keyed by the pid (a new directory every run,
+    nothing MIOpen learned ever reused); torchrun's default run id, the literal "none", is not a name either."""
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    for var in ("MIOPEN_USER_DB_PATH", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "CSPN_MIOPEN_DB_TAG"):
+        monkeypatch.delenv(var, raising=False)
+    d = conv_tuning.use_tuned_conv_db(rank=2)
+    assert os.path.basename(d) == "miopen_db_rank2" and str(os.getpid()) not in d
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    assert conv_tuning.use_tuned_conv_db(rank=2) == d
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("CSPN_MIOPEN_DB_TAG", "exp 7")
+    assert os.path.basename(conv_tuning.use_tuned_conv_db(rank=2)) == "miopen_db_exp_7_rank2"
+
+
 def test_database_copy_is_private_and_never_follows_planted_links(monkeypatch, tmp_path):
     """the per-rank copy must not live under a predictable name in the world-writable temp dir, must refuse
     a directory it does not own privately, must not follow a symlink planted where a file goes, and must keep what MIOpen

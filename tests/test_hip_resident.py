@@ -336,10 +336,11 @@ def test_volume_free_reverse_sweep_equals_the_sweep_on_the_published_volume(B, H
     F.check_resident_errors()
 
 
-def test_training_step_without_the_tap_volume_equals_the_one_with_it(c_oracle, monkeypatch):
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 24), (3, 61, 77, 9), (2, 40, 150, 24)], ids=["config2", "w77", "w150"])
+def test_training_step_without_the_tap_volume_equals_the_one_with_it(B, H, W, T, c_oracle, monkeypatch):
     """The default training path publishes S only (forward), rebuilds the taps in the reverse sweep and in the tail;
-    CSPN_TRAIN_VOLUME=1 keeps the 8-plane volume.  Same output, same gradients, bit for bit — plain and with a sparse depth."""
-    B, H, W, T = 24, 228, 304, 24
+    CSPN_TRAIN_VOLUME=1 keeps the 8-plane volume.  Same output, same gradients, bit for bit — plain and with a sparse depth, also
+    for widths that are not whole quads (the row-padding path, W_valid > 0, of the S-only forms)."""
     for sparse in (False, True):
         g, d, s = c_oracle.synthetic_inputs(230, B, H, W, 12, 500 if sparse else None)
         cot = dev(c_oracle.hash_normal(231, 9, (B, 1, H, W)))

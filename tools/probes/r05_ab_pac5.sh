@@ -18,7 +18,7 @@ def clock(fn, n=100):
         for _ in range(n): fn()
         e1.record(); e1.synchronize(); best = min(best, e0.elapsed_time(e1) * 1000 / n)
     return best
-m = pkg.CSPN_ours.AffinityPropagate(12); acc = ev.new_accumulator("cuda")
+m = pkg.CSPN_ours.AffinityPropagate(12, state_dtype=None); acc = ev.new_accumulator("cuda")
 out = []
 for (B, H, W) in [(24, 228, 304), (3, 228, 304)]:
     gd = torch.randn(B, 24, H, W, device="cuda").half(); x = (torch.rand(B, 1, H, W, device="cuda") * 10).half(); tg = (x.float() + 0.1).half()
