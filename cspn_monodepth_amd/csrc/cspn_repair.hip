@@ -229,9 +229,12 @@ int resident_repair_launch(const float* g, long bs, long cs, const float* d0, co
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         granted[slot][dev & 63].store(lds, std::memory_order_release);
     }
-    // one workgroup per CU (they loop over the tiles): the success path is n_cu workgroups that read one word and return
+    // a few workgroups that loop over the tiles: the success path — every launch of a healthy deployment — is `grid` workgroups
+    // that read one word and return, and its cost is their dispatch (rocprofv3, config 2's training step: 5.1 us with one workgroup
+    // per CU and 51 KB of LDS each; n_cu / 8 of them — 32 on an MI355X — keep the failure path at tens of milliseconds)
     int grid = B * a.tiles_x * a.tiles_y;
-    if (n_cu > 0 && grid > n_cu) grid = n_cu;
+    const int cap = n_cu >= 64 ? n_cu / 8 : 8;
+    if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(REP_THREADS), lds, static_cast<hipStream_t>(stream), a);
     HIP_OK(hipGetLastError());
     return 1;

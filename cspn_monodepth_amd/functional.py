@@ -10,6 +10,7 @@ import ctypes
 import math
 import os
 import threading
+import weakref
 import time
 
 import torch
@@ -628,22 +629,56 @@ def _poison_mask(t):
     return (t.view(torch.int32) == POISON_F32) if t.dtype == torch.float32 else (t.view(torch.int16) == POISON_F16)
 
 
+class _WeakT(object):
+    """A tensor of an old journal entry, held WEAKLY (through the tensor object that owns the storage: a view made inside this
+    package dies with the call, its base is the caller's) — enough to rebuild the same view if the caller still has it."""
+    __slots__ = ("ref", "size", "stride", "off")
+
+    def __init__(self, t):
+        base = t._base if t._base is not None else t
+        self.ref, self.size, self.stride, self.off = weakref.ref(base), t.size(), t.stride(), t.storage_offset()
+
+    def get(self):
+        base = self.ref()
+        return None if base is None else torch.as_strided(base, self.size, self.stride, self.off)
+
+
 class _JournalEntry(object):
-    """One resident launch that may still turn out to have timed out.  redo: re-runs the call on the multi-launch schedule into
-    the same output tensor (None: a training-form launch / anything that cannot be repaired after the fact); out: the tensor a
+    """One resident launch that may still turn out to have timed out.  redo(out, *inputs): re-runs the call on the multi-launch
+    schedule into `out` (None: a training-form launch / anything that cannot be repaired after the fact); out: the tensor a
     failed tile poisons; inputs: the tensors the repair would read, with their version counters at launch time — a repair from
-    inputs the caller has since overwritten in place would silently produce the result of ANOTHER batch."""
-    __slots__ = ("redo", "out", "inputs", "versions", "nbytes", "what")
+    inputs the caller has since overwritten in place would silently produce the result of ANOTHER batch.
+    The newest entries hold their tensors strongly (the failing call is found at the NEXT launch, when an eval loop has already
+    rebound its variables to the next batch); older ones are demoted to weak references (`demote`): a journal of unchecked
+    launches then pins at most _JOURNAL_STRONG_BYTES of the caller's tensors, and a late repair happens only if they still exist."""
+    __slots__ = ("redo", "out", "inputs", "versions", "nbytes", "what", "weak")
 
     def __init__(self, redo, out=None, inputs=(), what="resident launch", nbytes=None):
-        self.redo, self.out, self.what = redo, out, what
-        self.inputs = tuple(t for t in inputs if t is not None)
-        self.versions = tuple(t._version for t in self.inputs)
+        self.redo, self.out, self.what, self.weak = redo, out, what, False
+        self.inputs = tuple(inputs)
+        self.versions = tuple(None if t is None else t._version for t in self.inputs)
         self.nbytes = nbytes if nbytes is not None else (
-            sum(t.numel() * t.element_size() for t in self.inputs) + (0 if out is None else out.numel() * out.element_size()))
+            sum(t.numel() * t.element_size() for t in self.inputs if t is not None) + (0 if out is None else out.numel() * out.element_size()))
 
-    def inputs_untouched(self):
-        return all(t._version == v for t, v in zip(self.inputs, self.versions))
+    def demote(self):
+        if not self.weak and self.redo is not None:
+            self.out = None if self.out is None else _WeakT(self.out)
+            self.inputs = tuple(None if t is None else _WeakT(t) for t in self.inputs)
+            self.weak = True
+
+    def resolve(self):
+        """(out, inputs) as tensors; out None = the caller dropped it (nobody can read it: nothing to repair), inputs None = one of
+        them is gone (cannot be repaired)."""
+        if not self.weak:
+            return self.out, self.inputs
+        out = None if self.out is None else self.out.get()
+        ins = tuple(None if t is None else t.get() for t in self.inputs)
+        if any(t is None and w is not None for t, w in zip(ins, self.inputs)):
+            ins = None
+        return out, ins
+
+    def untouched(self, ins):
+        return all(t is None or t._version == v for t, v in zip(ins, self.versions))
 
 
 def _recover(dev, st):
@@ -664,7 +699,6 @@ def _recover(dev, st):
         lost, st["lost"] = st["lost"], False
         st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
         st["marks"] = []
-        st["jbytes"] = st["jbytes_since_mark"] = 0
         training = any(e.redo is None for e in journal)
         _note_fallback(training=training)
         stale = []
@@ -673,16 +707,24 @@ def _recover(dev, st):
         repaired, st["guarded_pending"] = st.get("guarded_pending", 0), 0
         with _device_guard(dev):
             for e in journal:
-                if e.redo is None or e.out is None or not _holds_poison(e.out):
-                    continue                       # finished cleanly (or cannot be looked at: handled below)
-                if not e.inputs_untouched():
+                if e.redo is None:
+                    continue                       # a training-form launch: raised below
+                out, ins = e.resolve()
+                if out is None or not _holds_poison(out):
+                    continue                       # finished cleanly — or the caller dropped the result: nobody can read it
+                if ins is None:
+                    stale.append(e.what + " (its input tensors no longer exist)")
+                    continue
+                if not e.untouched(ins):
                     stale.append(e.what)
                     continue
-                e.redo()
+                e.redo(out, *ins)
                 repaired += 1
-        if lost or training or stale or not repaired:
+        # (nothing repaired and nothing wrong with the journal: the failed call's result was dropped by its caller, or its guard
+        #  kernel has dealt with it — the event is counted and warned about, there is nothing to raise)
+        if lost or training or stale:
             why = ("a training-form launch" if training else
-                   "the inputs of the failed call (%s) were modified in place before the time-out was detected" % ", ".join(stale) if stale
+                   "the inputs of the failed call (%s) were modified in place (or freed) before the time-out was detected" % ", ".join(stale) if stale
                    else "graph replay / unchecked launches beyond the journal")
             raise ResidentLaunchTimeout(
                 "a weight-resident launch on cuda:%d timed out waiting for a neighbouring tile (the GPU was shared with another "
@@ -691,25 +733,34 @@ def _recover(dev, st):
                 "process (functional.set_resident): re-run the step." % (dev.index, why))
 
 
-_JOURNAL_MARK_BYTES = 64 << 20      # a completion mark at least every 64 MB of journaled tensors (or every 16 launches)
+_JOURNAL_STRONG_BYTES = 256 << 20     # tensors of unchecked launches held strongly (the newest entries; at least the last two)
 
 
 def _journal_add(dev, st, entry, stream):
-    """Remember how to repair the launch just issued on `stream`.  The journal never loses an entry that may still fail, and it
-    does not pin memory for long (32 unchecked config-2 batches were 2.5 GB): a completion mark (an event) is recorded
-    every 16 launches or 64 MB of journaled tensors, whichever comes first, every add drops what lies before the marks that have
-    completed (a poll, no wait), and a full journal waits for its oldest mark (normally long finished)."""
+    """Remember how to repair the launch just issued on `stream`.  The journal never loses an entry that may still fail: every
+    16th launch records an event behind itself, every add drops what lies before the marks that have completed (a poll, no
+    wait), and a full journal waits for its oldest mark (16+ launches back: normally long finished).  It does not pin the
+    caller's memory either (32 unchecked config-2 batches were 2.5 GB): only the newest entries — the last two, and
+    as many more as fit _JOURNAL_STRONG_BYTES — hold their tensors; older ones are demoted to weak references.  (A mark per
+    64 MB was tried first: an event record between two kernels costs ~2 us of stream time — config 3 read 76.8 instead of 72 us
+    per scored forward.)"""
     j = st["journal"]
     j.append(entry)
+    strong = 0
+    for k in range(len(j) - 1, -1, -1):            # newest first
+        e = j[k]
+        if e.weak:
+            break
+        strong += e.nbytes
+        if k < len(j) - 2 and strong > _JOURNAL_STRONG_BYTES:
+            e.demote()
     st["jcount"] = n = st.get("jcount", 0) + 1
-    st["jbytes_since_mark"] = since = st.get("jbytes_since_mark", 0) + entry.nbytes
     marks = st.setdefault("marks", [])
-    if n % 16 == 0 or since >= _JOURNAL_MARK_BYTES:
+    if n % 16 == 0:
         pool = st.setdefault("mark_pool", [])
         ev = pool.pop() if pool else torch.cuda.Event()
         ev.record(stream)
         marks.append([len(j), ev])
-        st["jbytes_since_mark"] = 0
     if marks and st["host_err_np"][0] == 0:
         cut = 0
         while marks:
@@ -795,7 +846,6 @@ def resident_supported(guidance, d0, sparse, T, plan=None, target=None):
 def _journal_clear(st):
     del st["journal"][:]
     st["lost"] = False
-    st["jbytes_since_mark"] = 0
     st["guarded_pending"] = 0
     st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
     st["marks"] = []
@@ -1122,15 +1172,17 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
 
     redo = None
     if not keep_history:
-        def redo():            # the same call on the multi-launch schedule, into the same tensors (bit-identical: §4.1b)
-            from . import evaluation
+        scored = score is not None
+
+        def redo(out, guidance, d0, sparse, tg):       # the same call on the multi-launch schedule, into the same tensors (bit-identical:
+            from . import evaluation                   # §4.1b); the tensors are handed in by the journal (it may hold them weakly)
             tgp = None if tg is None else tg.reshape(B, H, W)
-            if score is not None:
+            if scored:
                 _unscore_failed_launch(out, tgp, acc)
             res, _ = propagate_from_guidance(guidance, d0.reshape(B, H, W), None if sparse is None else sparse.reshape(B, H, W), T, blend,
                                              valid_w=valid_w)
             out.copy_(res)
-            if score is not None:
+            if scored:
                 evaluation.metric_sums(out, tgp, out=acc)
 
     ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo, out=out,
@@ -1243,14 +1295,16 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
                                         int(T), int(blend), _p(tg), _p(acc), 0 if acc is None else int(acc.shape[0]),
                                         None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    def redo():                # prepare + multi-launch propagation into the same tensor (fp32: the same bits; fp16 planes: the
-        from . import evaluation       # phase-rounded schedule, within fp16 rounding of the state of the dot-product form)
-        if score is not None:
+    scored = score is not None
+
+    def redo(out, guided, x0, sparse, tg):     # prepare + multi-launch propagation into the same tensor (fp32: the same bits; fp16 planes:
+        from . import evaluation               # the phase-rounded schedule, within fp16 rounding of the state of the dot-product form)
+        if scored:
             _unscore_failed_launch(out, tg, acc)
         wk, _ = pac_prepare(guided)
         res, _ = propagate(wk, x0, sparse, K, int(T), blend, plan=dtype_default_plan(K, wk.dtype, None))
         out.copy_(res)
-        if score is not None:
+        if scored:
             evaluation.metric_sums(out, tg, out=acc)
 
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
@@ -1664,7 +1718,10 @@ class _ScoredFast(object):
 
     def issue(self, guidance, d0, sparse, target, acc):
         st = self.st
-        if (_EVENT_LOG is not None or _RESIDENT_SPIN_LIMIT or self.work is None or st["work"].get(self.wkey) is not self.work
+        work = st["work"].get(self.wkey)
+        if work is not self.work:                      # the workspace cache was started over (more than 16 shapes): pick up the new one
+            self.work = work
+        if (_EVENT_LOG is not None or _RESIDENT_SPIN_LIMIT or work is None
                 or torch._C._cuda_getDevice() != self.idx or torch._C._cuda_isCurrentStreamCapturing()):
             return None
         raw = torch._C._cuda_getCurrentRawStream(self.idx)
@@ -1684,8 +1741,8 @@ class _ScoredFast(object):
                 st["dirty"] = True
                 st["last_reports"] = False
 
-                def redo():        # the same call on the multi-launch schedule, into the same tensors (bit-identical: DESIGN.md §4.1b)
-                    from . import evaluation
+                def redo(out, guidance, d0, sparse, target):       # the same call on the multi-launch schedule, into the same tensors
+                    from . import evaluation                       # (bit-identical: DESIGN.md §4.1b)
                     tgp = target.reshape(B, H, W)
                     _unscore_failed_launch(out, tgp, acc)
                     res, _ = propagate_from_guidance(guidance, d0.reshape(B, H, W), None if sparse is None else sparse.reshape(B, H, W), T, blend)

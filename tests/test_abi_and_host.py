@@ -183,6 +183,36 @@ def test_production_shapes_keep_their_resident_instances():
         assert tuple(p[k] for k in keys) == (4, 2, 10, 152, 23, 1, 12, 2) and p["threads"] == 768, p
 
 
+def test_journal_entries_demote_to_weak_references():
+    """Host logic of the resident launches' journal (no GPU needed): an old entry holds its tensors weakly — through the tensor
+    that owns the storage, so that a view made inside the package can be rebuilt — and reports a dropped output as "nothing to
+    repair" and dropped inputs as "cannot be repaired"; version counters tell an in-place overwrite."""
+    import gc
+    from cspn_monodepth_amd import functional as F
+    g = torch.arange(2 * 12 * 4 * 8, dtype=torch.float32).reshape(2, 12, 4, 8)
+    d = torch.ones(2, 1, 4, 8)
+    d0 = d[:, 0]                                       # a view, as functional._plane makes it
+    out = torch.zeros(2, 4, 8)
+    e = F._JournalEntry(lambda *a: None, out, (g, d0, None, None), "test")
+    assert e.nbytes == (g.numel() + d0.numel() + out.numel()) * 4 and not e.weak
+    e.demote()
+    assert e.weak
+    del d0
+    gc.collect()
+    o2, ins = e.resolve()
+    assert o2.data_ptr() == out.data_ptr() and ins[0].data_ptr() == g.data_ptr()
+    assert ins[1].data_ptr() == d.data_ptr() and tuple(ins[1].shape) == (2, 4, 8) and ins[2] is None      # the view, rebuilt from its base
+    assert e.untouched(ins)
+    g.add_(1.0)
+    assert not e.untouched(e.resolve()[1])            # an in-place overwrite shows in the version counter
+    del out, o2
+    gc.collect()
+    assert e.resolve()[0] is None                     # the result was dropped: nobody can read it
+    del g, ins
+    gc.collect()
+    assert e.resolve()[1] is None                     # an input is gone: the call cannot be re-run
+
+
 def test_bench_cpu_binding_narrows_and_restores_the_affinity_mask():
     """bench.py --cpu-bind auto: a rank's host threads go to its share of the first allowed cores; the CPU baseline leg gets the
     whole mask back (full_affinity), and the reported host budget is the original one."""

@@ -539,23 +539,27 @@ def test_guard_recomputation_on_reference_goldens(name):
 
 
 def test_journal_does_not_pin_batches(c_oracle):
-    """the journal of unchecked launches must not keep tens of batches of inputs alive.  A completion mark is
-    recorded at least every 64 MB of journaled tensors and finished entries are dropped on the next add: after 40 config-2-sized
-    calls (80 MB each) and a synchronisation the journal holds at most the last couple of calls."""
+    """the journal of unchecked launches must not keep tens of batches of inputs alive.  Only the newest
+    entries hold their tensors (the last two and what fits 256 MB); older ones are demoted to weak references, and entries
+    behind a completed mark (one every 16 launches) are dropped on the next add: after 40 config-2-sized calls (80 MB each) at
+    most 4 entries pin tensors; it was up to 32 batches = 2.5 GB."""
     gt, dt, _ = _config2(c_oracle, seed=411)
     m = pkg.CSPN_new.AffinityPropagate(24, 3)
     st = F._resident_state(gt.device)
     with torch.no_grad(), resident("on"):
-        with guard(False):                          # host-repaired calls: their entries hold the call's tensors
+        with guard(False):                          # host-repaired calls: their entries refer to the call's tensors
             for _ in range(40):
                 m(gt, dt)
-            assert len(st["journal"]) <= F._JOURNAL_MAX
+            j = st["journal"]
+            assert len(j) <= F._JOURNAL_MAX
+            strong = [e for e in j if not e.weak]
+            assert len(strong) <= 4 and sum(e.nbytes for e in strong[:-2]) <= F._JOURNAL_STRONG_BYTES, (len(strong), len(j))
             torch.cuda.synchronize()
             m(gt, dt)
-            assert len(st["journal"]) <= 2, len(st["journal"])
+            assert len(st["journal"]) <= 16, len(st["journal"])     # everything behind the completed marks is gone
             F.ensure_resident_ok()
             assert not st["journal"]
-        for _ in range(20):                         # guarded calls (the default for plain inference): nothing is kept alive at all
+        for _ in range(20):                         # guarded calls (the default for plain inference): nothing is kept at all
             m(gt, dt)
         assert not st["journal"] and st["guarded_pending"] == 20    # counted, not kept: no entry, no tensor reference
         F.ensure_resident_ok()

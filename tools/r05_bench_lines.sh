@@ -8,6 +8,9 @@ cd $R
 run() { n=$1; shift; timeout 400 "$@" 2>$O/$n.err | tail -1 > $O/r05_bench_$n.json; }
 run default_driver python bench.py --steps 20 --warmup 5
 run default python bench.py --steps 200 --warmup 20 --no-cpu-baseline
+run default_bind_off python bench.py --steps 200 --warmup 20 --no-cpu-baseline --cpu-bind off
+run default_driver_bind_off python bench.py --steps 20 --warmup 5 --cpu-bind off
+run default_bind_auto python bench.py --steps 200 --warmup 20 --no-cpu-baseline --cpu-bind auto
 CSPN_RESIDENT=off run default_multilaunch python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train-leg --cold-sets 0
 run sparse python bench.py --steps 200 --warmup 20 --no-cpu-baseline --sparse
 run kitti python bench.py --workload kitti --steps 100 --warmup 10 --no-cpu-baseline
