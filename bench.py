@@ -147,7 +147,8 @@ def bind_cpus(local_rank, local_world, mode):
     On the 256-thread hosts of the GPU boxes the scheduler otherwise spreads them over the sockets' CCDs, and a launch-rate-bound
     leg then depends on where they happen to land: the training-shaped leg read 213-217 us per pass in some processes and 265-290 us
     in others with IDENTICAL kernel times (rocprofv3: 86 + 61 + 60 us in every run) — bound to four cores it reads 213-217 us in
-    every run, and the headline value gains ~2 % (same-box A/B, five alternating runs; tools/probes/r04_train_bimodal.sh).
+    every run, and the headline value gains ~2 % (same-box A/B, five alternating runs; round 4).  Round 5 removed the cause (the leg
+    is GPU-bound now, see --cpu-bind) and the binding is opt-in.
     What `numactl` / `taskset` in a launch script would do; --cpu-bind off leaves the mask alone.  (The block is the rank's
     share of the FIRST allowed cores on purpose: picking the idlest block of the moment — /proc/stat over 40 ms — was tried and
     is worse, twice it chose cores 4-7 of a box and the leg read 600-720 us: idle cores sit in deep C-states and the autograd
@@ -496,8 +497,12 @@ def main():
                     help="--workload train: torch.backends.cudnn.benchmark (MIOpen find mode) as the reference's main.py:37; "
                          "slow first steps (minutes)")
     ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
-    ap.add_argument("--cpu-bind", choices=("auto", "off"), default="auto",
-                    help="auto: bind the rank's host threads to four adjacent cores of the allowed set (see bind_cpus); off: leave the mask alone")
+    # round 5: the default is OFF — the training-shaped leg is GPU-bound since the host path through CSPN3Function was cut from 217 to
+    # 181 us per pass (it no longer matters where the scheduler puts the threads: 217.3 us unbound against 220.2 bound, headline 514.1 k
+    # against 514.4 k maps/s at 200 steps, profiles/r05_bench_default_bind_{off,auto}.json), and a binding the harness applies is a
+    # property of the harness, not of the product
+    ap.add_argument("--cpu-bind", choices=("auto", "off"), default="off",
+                    help="off (default): leave the affinity mask alone; auto: bind the rank's host threads to four adjacent cores of the allowed set (see bind_cpus)")
     args = ap.parse_args()
     cpu_bound = bind_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))),
                           args.cpu_bind)
