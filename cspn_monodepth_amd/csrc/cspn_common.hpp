@@ -39,8 +39,13 @@ int pac_s2_grad_kernel(const void* gout, const void* in, void* gk, int dtype, in
 bool resident_repair_fits(int T);
 int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, float* hist, float* s_out,
                            float* w_out, const float* s_in, int mode, const unsigned* abort_word, unsigned seq, int B, int H, int W, int Wv,
-                           int T, int blend, int n_cu, void* stream);      // mode 0: inference, 2: training forward, 3 / 4: reverse sweep from a tap volume / from
+                           int T, int blend, int n_cu, void* stream, const float* target = nullptr, double* acc = nullptr, int nslots = 0);
+                           // mode 0: inference, 1: inference + fused metrics, 2: training forward, 3 / 4: reverse sweep from a tap volume / from
                                                                                  // guidance + S, 10 / 12: softmax-weight (CSPN_ours K = 3) inference / training forward
+// ... and of cspnk_forward_resident's unscored inference calls (round_every: the steps between two roundings of the state to the plane dtype)
+bool kres_repair_fits(int K, int T);
+int kres_repair_launch(const void* g, int g_dtype, int K, const void* x0, const void* sparse, void* out, int state_dtype,
+                       const unsigned* abort_word, unsigned seq, int B, int H, int W, int T, int round_every, int blend, int n_cu, void* stream);
 // cspn_debug.hip: the poisoned-LDS debugging aid (include/cspn_hip.h: cspn_debug_set_lds_poison)
 extern int g_lds_poison_on;
 void lds_poison(hipStream_t st);

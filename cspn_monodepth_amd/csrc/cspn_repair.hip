@@ -25,6 +25,7 @@ struct RepArgs {
     const float* g; long g_bs, g_cs;
     const float* d0; const float* sparse; float* out;
     float* hist; float* s_out; float* w_out; const float* s_in;
+    const float* target; double* macc; int nslots;      // MODE 1: the fused depth metrics of the pixels the failed launch did not score
     const unsigned* abort_word; unsigned seq;
     int B, H, W, Wv, T, tiles_x, tiles_y;
 };
@@ -37,7 +38,9 @@ __device__ __forceinline__ float rcp_as_forward(float S) {
     return okr ? r : 1.0f / S;
 }
 
-// MODE 0: inference (refined depth -> out).  MODE 2: the training forward — every step's state goes to its history plane, the
+// MODE 0: inference (refined depth -> out).  MODE 1: inference with the depth metrics fused — the launch that gave up has scored the
+// tiles that finished and poisoned the others, so the re-computation adds the metric terms of exactly the pixels it finds poisoned
+// (summation order differs from the fused epilogue's: the sums agree to ~1e-7, the refined depth to the bit).  MODE 2: the training forward — every step's state goes to its history plane, the
 // normaliser S (and, when asked for, the taps) is published.  MODE 4: the volume-free reverse sweep G_t = stencil^T((1-m) G_{t+1}) on
 // the taps |g_j[p]| / S[p + off_j]; d0 is G_T, the history receives G_{T-1} .. G_0, (1-m) G travels.  MODE 3: the same sweep on taps
 // gathered from a forward tap volume (a.g = [B,8,H,W]): tap j = w_{7-j}[p + off_j].
@@ -47,7 +50,10 @@ __device__ __forceinline__ float rcp_as_forward(float S) {
 template <int BLEND, int MODE, int PAC>
 __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepArgs a) {
     if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) return;      // the call finished: nothing to do
-    constexpr bool TRANSG = MODE == 4, TRANS = MODE == 3 || MODE == 4, HIST = MODE != 0;
+    constexpr bool TRANSG = MODE == 4, TRANS = MODE == 3 || MODE == 4, HIST = MODE >= 2, SCORE = MODE == 1;
+    float mf[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) mf[k] = 0.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int T = a.T, R = REP_TILE + 2 * T, H = a.H, W = a.W, Wv = a.Wv;
     float* cur = lds;
@@ -185,8 +191,117 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
             float* __restrict__ ob = a.out + b * HW;
             for (int i = threadIdx.x; i < REP_TILE * REP_TILE; i += REP_THREADS) {
                 const int ly = i / REP_TILE, lx = i - ly * REP_TILE, y = ty * REP_TILE + ly, x = tx * REP_TILE + lx;
-                if (y < H && x < Wv) ob[(size_t)y * W + x] = cur[(T + ly) * R + T + lx];
+                if (y < H && x < Wv) {
+                    const float v = cur[(T + ly) * R + T + lx];
+                    if (SCORE && __float_as_uint(ob[(size_t)y * W + x]) == CSPN_POISON_F32) metric_terms(v, a.target[b * HW + (size_t)y * W + x], mf);
+                    ob[(size_t)y * W + x] = v;
+                }
             }
+        }
+    }
+    if (SCORE) {
+        __syncthreads();
+        float* part = lds;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float v = wave_sum_to_lane63(mf[k]);
+            if (lane == 63) part[wave * 10 + k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 10) {
+            double v = 0.0;
+            for (int w = 0; w < REP_THREADS / 64; ++w) v += (double)part[w * 10 + threadIdx.x];
+            if (v != 0.0) atomicAdd(a.macc + (size_t)(blockIdx.x % a.nslots) * 10 + threadIdx.x, v);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ K x K softmax forms (CSPN_ours)
+// The guard of cspnk_forward_resident's unscored inference calls (round 5): same structure — 32 x 32 output tiles with the T * (K / 2)
+// pixel halo of T steps in LDS, nothing to wait for — with the arithmetic of the FMA kernel cspnk_resident: softmax over the K*K-1
+// channels at the pixel itself (fp16 guidance: float(half) - max, 2^(d log2 e), sum in channel order, refined reciprocal, ONE rounding
+// to half; fp32 guidance: the two-piece exponential), (1-m) folded into the taps, one FMA per tap in row-major tap order from 0,
+// + m * x0, the state rounded to the plane dtype where that kernel rounds it: after every `round_every` steps (its phase length) and
+// at the end.  For the FMA step form the re-computed depth is therefore the multi-launch schedule's bits; for the dot-product form
+// (cspnk_d2: state rounded after EVERY step, two taps per v_dot2_f32_f16) round_every = 1 gives the half-precision recurrence with
+// one FMA per tap — within the fp16 tolerance of the configuration, like the host repair of that form.
+struct KRepArgs {
+    const void* g; const void* x0; const void* sparse; void* out;
+    const unsigned* abort_word; unsigned seq;
+    int B, H, W, T, round_every, tiles_x, tiles_y;
+};
+template <typename T> __device__ __forceinline__ float ldf(const void* p, size_t i);
+template <> __device__ __forceinline__ float ldf<float>(const void* p, size_t i) { return static_cast<const float*>(p)[i]; }
+template <> __device__ __forceinline__ float ldf<__half>(const void* p, size_t i) { return __half2float(static_cast<const __half*>(p)[i]); }
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__half>(float v) { return __half2float(__float2half_rn(v)); }
+__device__ __forceinline__ void stf(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void stf(__half* p, size_t i, float v) { p[i] = __float2half_rn(v); }
+
+template <int K, typename GT, typename ST, int BLEND>
+__global__ __launch_bounds__(REP_THREADS) void cspnk_resident_repair(const KRepArgs a) {
+    if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) return;      // the call finished: nothing to do
+    constexpr int RK = K / 2, NT = K * K - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.T, HALO = T * RK, R = REP_TILE + 2 * HALO, H = a.H, W = a.W;
+    float* cur = lds;
+    float* nxt = lds + (size_t)R * R;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const size_t HW = (size_t)H * W;
+    for (int t = blockIdx.x; t < a.B * tiles; t += gridDim.x) {
+        const int b = t / tiles, tr = t - b * tiles, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int ry0 = ty * REP_TILE - HALO, rx0 = tx * REP_TILE - HALO;
+        const size_t gbase = (size_t)b * NT * HW, pbase = (size_t)b * HW;
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * R; i += REP_THREADS) {
+            const int ry = i / R, rx = i - ry * R, y = ry0 + ry, x = rx0 + rx;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            cur[i] = in ? ldf<ST>(a.x0, pbase + (size_t)y * W + x) : 0.f;
+            nxt[i] = 0.f;
+        }
+        __syncthreads();
+        for (int s = 1; s <= T; ++s) {
+            const int lo = s * RK, n = R - 2 * lo;
+            const bool round_now = (s % a.round_every) == 0 || s == T;
+            for (int i = threadIdx.x; i < n * n; i += REP_THREADS) {
+                const int ry = lo + i / n, rx = lo + i % n, y = ry0 + ry, x = rx0 + rx;
+                float u = 0.f;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const size_t p = (size_t)y * W + x;
+                    float w[NT];
+                    float mx = -INFINITY, den = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) { w[c] = ldf<GT>(a.g, gbase + (size_t)c * HW + p); mx = fmaxf(mx, w[c]); }
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) { w[c] = softmax_exp<GT>(w[c] - mx); den += w[c]; }
+                    const float inv = reciprocal_refined(den);
+                    float m = 0.f;
+                    if (BLEND) m = sgnf(ldf<ST>(a.sparse, pbase + p));
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        w[c] = softmax_weight<GT>(w[c], inv);
+                        if (BLEND) w[c] = round_to<GT>(w[c] * (1.f - m));      // 1-m in {0, 1, 2}: exact in either tap dtype
+                    }
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        const int lin = c < NT / 2 ? c : c + 1, dy = lin / K - RK, dx = lin % K - RK;
+                        u = fmaf(w[c], cur[(ry + dy) * R + rx + dx], u);
+                    }
+                    if (BLEND) u = __fadd_rn(u, __fmul_rn(m, ldf<ST>(a.x0, pbase + p)));
+                    if (round_now) u = round_to<ST>(u);
+                }
+                nxt[ry * R + rx] = u;
+            }
+            __syncthreads();
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        ST* ob = static_cast<ST*>(a.out) + pbase;
+        for (int i = threadIdx.x; i < REP_TILE * REP_TILE; i += REP_THREADS) {
+            const int ly = i / REP_TILE, lx = i - ly * REP_TILE, y = ty * REP_TILE + ly, x = tx * REP_TILE + lx;
+            if (y < H && x < W) stf(ob, (size_t)y * W + x, cur[(HALO + ly) * R + HALO + lx]);
         }
     }
 }
@@ -199,16 +314,16 @@ bool resident_repair_fits(int T) { return T >= 1 && (size_t)2 * (REP_TILE + 2 * 
 
 int resident_repair_launch(const float* g, long bs, long cs, const float* d0, const float* sparse, float* out, float* hist, float* s_out,
                            float* w_out, const float* s_in, int mode, const unsigned* abort_word, unsigned seq, int B, int H, int W, int Wv,
-                           int T, int blend, int n_cu, void* stream) {
+                           int T, int blend, int n_cu, void* stream, const float* target, double* acc, int nslots) {
     if (!resident_repair_fits(T)) return fail("cspn3_forward_resident: the guard re-computes at most 54 steps (T=%d)", T);
-    if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 10 && mode != 12) return fail("cspn3_forward_resident: the guard has no form for this launch");
-    RepArgs a{g, bs, cs, d0, sparse, out, hist, s_out, w_out, s_in, abort_word, seq, B, H, W, Wv, T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 10 && mode != 12) return fail("cspn3_forward_resident: the guard has no form for this launch");
+    RepArgs a{g, bs, cs, d0, sparse, out, hist, s_out, w_out, s_in, target, acc, nslots > 0 ? nslots : 1, abort_word, seq, B, H, W, Wv, T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
     const size_t lds = (size_t)2 * (REP_TILE + 2 * T) * (REP_TILE + 2 * T) * sizeof(float);
-    static std::atomic<size_t> granted[12][64];
+    static std::atomic<size_t> granted[14][64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
     // slots: (inference, training forward, sweep from guidance + S, sweep from a tap volume, softmax inference, softmax training forward) x blend
-    const int form = mode == 0 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : mode == 3 ? 3 : mode == 10 ? 4 : 5;
+    const int form = mode == 0 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : mode == 3 ? 3 : mode == 10 ? 4 : mode == 12 ? 5 : 6;
     const int slot = 2 * form + (blend ? 1 : 0);
     void (*kern)(RepArgs) = nullptr;
     switch (slot) {
@@ -223,7 +338,9 @@ int resident_repair_launch(const float* g, long bs, long cs, const float* d0, co
         case 8: kern = cspn3_resident_repair<0, 0, 1>; break;
         case 9: kern = cspn3_resident_repair<1, 0, 1>; break;
         case 10: kern = cspn3_resident_repair<0, 2, 1>; break;
-        default: kern = cspn3_resident_repair<1, 2, 1>; break;
+        case 11: kern = cspn3_resident_repair<1, 2, 1>; break;
+        case 12: kern = cspn3_resident_repair<0, 1, 0>; break;
+        default: kern = cspn3_resident_repair<1, 1, 0>; break;
     }
     if (lds > 64 * 1024 && granted[slot][dev & 63].load(std::memory_order_acquire) < lds) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -238,6 +355,47 @@ int resident_repair_launch(const float* g, long bs, long cs, const float* d0, co
     hipLaunchKernelGGL(kern, dim3(grid), dim3(REP_THREADS), lds, static_cast<hipStream_t>(stream), a);
     HIP_OK(hipGetLastError());
     return 1;
+}
+
+
+bool kres_repair_fits(int K, int T) {
+    const int R = REP_TILE + 2 * T * (K / 2);
+    return T >= 1 && (K == 3 || K == 5) && (size_t)2 * R * R * sizeof(float) <= 160 * 1024;
+}
+
+template <int K, typename GT, typename ST>
+static int kres_repair_launch_t(const KRepArgs& a, int blend, size_t lds, int grid, hipStream_t st) {
+    static std::atomic<size_t> granted[2][64];
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    void (*kern)(KRepArgs) = blend ? cspnk_resident_repair<K, GT, ST, 1> : cspnk_resident_repair<K, GT, ST, 0>;
+    if (lds > 64 * 1024 && granted[blend ? 1 : 0][dev & 63].load(std::memory_order_acquire) < lds) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted[blend ? 1 : 0][dev & 63].store(lds, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(REP_THREADS), lds, st, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int kres_repair_launch(const void* g, int g_dtype, int K, const void* x0, const void* sparse, void* out, int state_dtype,
+                       const unsigned* abort_word, unsigned seq, int B, int H, int W, int T, int round_every, int blend, int n_cu, void* stream) {
+    if (!kres_repair_fits(K, T)) return fail("cspnk_forward_resident: the guard re-computes at most T * (K / 2) = 54 halo pixels (K=%d, T=%d)", K, T);
+    KRepArgs a{g, x0, sparse, out, abort_word, seq, B, H, W, T, round_every > 0 ? round_every : T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
+    const int R = REP_TILE + 2 * T * (K / 2);
+    const size_t lds = (size_t)2 * R * R * sizeof(float);
+    int grid = B * a.tiles_x * a.tiles_y;
+    const int cap = n_cu >= 64 ? n_cu / 8 : 8;
+    if (grid > cap) grid = cap;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool gh = g_dtype == CSPN_F16, sh = state_dtype == CSPN_F16;
+    if (!gh && sh) return fail("cspnk_forward_resident: fp32 guidance with fp16 planes has no kernel");
+    if (K == 3) {
+        if (gh) return sh ? kres_repair_launch_t<3, __half, __half>(a, blend, lds, grid, st) : kres_repair_launch_t<3, __half, float>(a, blend, lds, grid, st);
+        return kres_repair_launch_t<3, float, float>(a, blend, lds, grid, st);
+    }
+    if (gh) return sh ? kres_repair_launch_t<5, __half, __half>(a, blend, lds, grid, st) : kres_repair_launch_t<5, __half, float>(a, blend, lds, grid, st);
+    return kres_repair_launch_t<5, float, float>(a, blend, lds, grid, st);
 }
 
 }  // namespace cspn_detail

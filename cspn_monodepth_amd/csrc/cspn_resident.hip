@@ -1163,9 +1163,9 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     const bool clean = regions_inside_image(g, H, W, a.Wv, T);
     // (refused rather than ignored: a host that asked for the guard relies on `out` being complete for GPU-side consumers)
     // mode: 0 / 1 / 2 inference / scored / training forward, 3 / 7 reverse sweep from a tap volume / from guidance + S, 4 / 5 / 6 the softmax forms
-    if (rp.guard && ((mode != 0 && mode != 2 && mode != 3 && mode != 7 && mode != 4 && mode != 6) || ((mode == 0 || mode == 4) && !out) ||
+    if (rp.guard && ((mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 7 && mode != 4 && mode != 6) || ((mode == 0 || mode == 1 || mode == 4) && !out) ||
                      !cspn_detail::resident_repair_fits(T)))
-        return fail("cspn3_forward_resident: plan->guard serves the unscored forms (inference, training forward, reverse sweeps) of T <= 54 steps");
+        return fail("cspn3_forward_resident: plan->guard serves inference (plain / scored), the training forward and the reverse sweeps, T <= 54 steps");
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
         a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
@@ -1189,7 +1189,8 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     }
     if (rp.guard)
         return cspn_detail::resident_repair_launch(a.g, bs, cs, a.d0, a.sparse, a.out, a.hist, a.s_out, a.w_out, a.s_in,
-                                                   mode == 7 ? 4 : mode == 4 ? 10 : mode == 6 ? 12 : mode, a.status, seq, B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st);
+                                                   mode == 7 ? 4 : mode == 4 ? 10 : mode == 6 ? 12 : mode, a.status, seq, B, H, W, a.Wv, T, blend ? 1 : 0, ncu, st,
+                                                   a.target, a.macc, a.nslots);
     return 1;
 }
 

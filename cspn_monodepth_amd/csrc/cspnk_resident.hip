@@ -848,7 +848,8 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         return cspn_detail::resident_pac3_f32(guided, x0, sparse, out, nullptr, nullptr, work, seq, host_err, B, H, W, T, blend, target, acc,
                                               nslots, &qp, stream);
     }
-    if (rp.guard) return fail("cspnk_forward_resident: plan->guard exists for K = 3 with fp32 guidance only (the oct kernels have no re-computation form)");
+    if (rp.guard && (acc || !cspn_detail::kres_repair_fits(K, T)))
+        return fail("cspnk_forward_resident: plan->guard serves unscored calls with T * (K / 2) <= 54");
     if (rp.tiles_x > 0 && rp.tiles_y > 0 && rp.tile_w > 0 && rp.tile_h > 0 && rp.steps_per_phase > 0 && rp.images_per_launch > 0) {
         const int Se = rp.steps_per_phase > T ? T : rp.steps_per_phase;
         if (!kgeom_fill(K, g_dtype, H, W, T, blend, ncu, B, Se, rp.tiles_x, rp.tiles_y, rp.tile_w, rp.tile_h, rp.threads > 0 ? rp.threads : KRES_THREADS, &g) ||
@@ -887,7 +888,10 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         a.nb = g.imgs_per_launch < B ? g.imgs_per_launch : B;
         a.rounds = ceil_div(B, a.nb);
         a.last_chunk = 1;
-        return cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, score, clean ? 1 : 0, stream);
+        if (!cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, score, clean ? 1 : 0, stream)) return 0;
+        // (the dot-product form rounds the state to half after every step)
+        if (rp.guard) return cspn_detail::kres_repair_launch(guided, g_dtype, K, x0, sparse, out, state_dtype, a.status, seq, B, H, W, T, 1, blend ? 1 : 0, ncu, stream);
+        return 1;
     }
     for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
         a.b0 = b0;
@@ -906,6 +910,8 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         }
         if (!ok) return 0;
     }
+    // (the FMA form rounds the state to the plane dtype at its phase boundaries)
+    if (rp.guard) return cspn_detail::kres_repair_launch(guided, g_dtype, K, x0, sparse, out, state_dtype, a.status, seq, B, H, W, T, g.S, blend ? 1 : 0, ncu, stream);
     return 1;
 }
 

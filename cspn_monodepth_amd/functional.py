@@ -548,13 +548,17 @@ _RESIDENT_SPIN_LIMIT = 0   # test hook: polls before a neighbour wait gives up (
 # launch is re-computed ON THE STREAM before anything can read it.  The scored calls (consumer = this package's metric gather,
 # which repairs on the host first) and the training forms do not.  Costs one empty launch (~2 us); CSPN_RESIDENT_GUARD=0 or
 # set_resident_guard(False) for A/B runs.
-_RESIDENT_GUARD = os.environ.get("CSPN_RESIDENT_GUARD", "1") != "0"
+# "all" (CSPN_RESIDENT_GUARD=all): the scored forward carries the guard as well (its re-computation also adds the metric terms of
+# the pixels the failed launch left unscored) — for a host that hands the refined depth of forward_scored to other GPU work before it
+# gathers the metrics; it costs the headline path the same 1-2 us per call, which is why it is not the default.
+_RESIDENT_GUARD = {"0": False, "all": "all"}.get(os.environ.get("CSPN_RESIDENT_GUARD", "1"), True)
 _GUARD_MAX_T = 54
 
 
 def set_resident_guard(enabled):
+    """True (default): every unscored resident call carries the device-side guard; "all": the scored forward too; False: none."""
     global _RESIDENT_GUARD
-    _RESIDENT_GUARD = bool(enabled)
+    _RESIDENT_GUARD = "all" if enabled == "all" else bool(enabled)
 
 
 def set_resident(mode):
@@ -1151,7 +1155,9 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     tg, acc = score if score is not None else (None, None)
     rp = None
-    guard = int(_RESIDENT_GUARD and score is None and int(T) <= _GUARD_MAX_T) if guard is None else int(guard)
+    if guard is None:
+        guard = int(bool(_RESIDENT_GUARD) and (score is None or _RESIDENT_GUARD == "all") and int(T) <= _GUARD_MAX_T)
+    guard = int(guard)
     if _plan is not None and not _RESIDENT_SPIN_LIMIT:
         rp = _plan                                     # the caller's cached (guarded) plan: CSPN3Function's fast path
     elif steps_per_phase or spin_limit or debug_stamps is not None or threads:
@@ -1260,7 +1266,7 @@ def set_kres_step_form(form):
 
 
 def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, spin_limit=0, debug_stamps=None, threads=0,
-                         step_form=None):
+                         step_form=None, guard=None):
     """CSPN_ours.AffinityPropagate.forward (CSPN_ours.py:24-54) as weight-resident launches (cspnk_forward_resident):
     guided [B,K*K-1,H,W] fp16, x0 / sparse [B,H,W] fp16 or fp32 -> refined [B,H,W] of that dtype; `score=(target, acc)`
     fuses the depth metrics into the last launch.  step_form: None = the module setting (set_kres_step_form), or
@@ -1276,9 +1282,11 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
     form = _KRES_STEP_FORM if step_form is None else int(step_form)
     if form == _lib.STEP_DOT2 and not (K == 5 and guided.dtype == torch.float16 and x0.dtype == torch.float16):
         form = _lib.STEP_AUTO                      # a process-wide "dot2" only pins the calls that have the kernel
-    # the K = 3 / fp32-guidance model (what the reference's unet_ours runs) is served by the quad kernel, which has the device-side
-    # guard (csrc/cspn_repair.hip: softmax forms); the oct kernels (fp16 guidance, K = 5) keep the host repair
-    guard = int(_RESIDENT_GUARD and score is None and K == 3 and guided.dtype == torch.float32 and int(T) <= _GUARD_MAX_T)
+    # every unscored K x K call carries the device-side guard (csrc/cspn_repair.hip: the softmax forms of the quad kernel for the K = 3 /
+    # fp32-guidance model the reference's unet_ours runs, cspnk_resident_repair for the oct kernels); scored calls keep the host repair
+    if guard is None:
+        guard = int(bool(_RESIDENT_GUARD) and score is None and int(T) * (K // 2) <= _GUARD_MAX_T)
+    guard = int(guard)
     if steps_per_phase or spin_limit or debug_stamps is not None or threads:
         rp = _lib.cspn_resident_plan()
         rp.steps_per_phase = int(steps_per_phase)
@@ -1702,7 +1710,8 @@ class _ScoredFast(object):
     state, the workspace, the constant arguments of the C call.  `issue` is _resident_launch + forward_resident with nothing left
     to look up; whatever it does not handle (another device current, a stream change, HIP-graph capture, an event log, a sequence
     wrap, an evicted workspace) returns None and the caller takes the general path."""
-    __slots__ = ("plan", "dev", "idx", "st", "work", "wkey", "B", "H", "W", "T", "blend", "gs0", "gs1", "nslots", "nbytes", "what", "cfunc")
+    __slots__ = ("plan", "plan_guarded", "dev", "idx", "st", "work", "wkey", "B", "H", "W", "T", "blend", "gs0", "gs1", "nslots", "nbytes",
+                 "what", "cfunc")
 
     def __init__(self, plan, guidance, T, blend, acc):
         B, C, H, W = guidance.shape
@@ -1715,6 +1724,7 @@ class _ScoredFast(object):
         self.nbytes = (guidance.numel() + (3 + int(bool(blend))) * B * H * W) * 4
         self.what = "cspn3_forward_resident %dx%dx%d (scored)" % (B, H, W)
         self.cfunc = _lib.lib().cspn3_forward_resident
+        self.plan_guarded = _with_spin_limit(plan, guard=1) if int(T) <= _GUARD_MAX_T and not _RESIDENT_SPIN_LIMIT else None
 
     def issue(self, guidance, d0, sparse, target, acc):
         st = self.st
@@ -1729,6 +1739,7 @@ class _ScoredFast(object):
             return None
         out = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
         B, H, W, T, blend = self.B, self.H, self.W, self.T, self.blend
+        guarded = _RESIDENT_GUARD == "all" and self.plan_guarded is not None
         with st["lock"]:
             if st["host_err_np"][0] != 0:
                 _recover(self.dev, st)
@@ -1736,10 +1747,13 @@ class _ScoredFast(object):
             st["seq"] = seq + _RES_SEQ_STEP
             ok = self.cfunc(guidance.data_ptr(), self.gs0, self.gs1, d0.data_ptr(), None if sparse is None else sparse.data_ptr(), out.data_ptr(),
                             None, None, None, self.work.data_ptr(), seq, st["host_err_ptr"], B, H, W, 0, T, blend, target.data_ptr(),
-                            acc.data_ptr(), self.nslots, self.plan, raw)
+                            acc.data_ptr(), self.nslots, self.plan_guarded if guarded else self.plan, raw)
             if ok:
                 st["dirty"] = True
                 st["last_reports"] = False
+            if ok and guarded:                     # the guard re-computes the depth AND the missing metric terms on the stream: no entry
+                st["guarded_pending"] = st.get("guarded_pending", 0) + 1
+            elif ok:
 
                 def redo(out, guidance, d0, sparse, target):       # the same call on the multi-launch schedule, into the same tensors
                     from . import evaluation                       # (bit-identical: DESIGN.md §4.1b)
@@ -1777,8 +1791,8 @@ def cspn3_refine_and_score(guidance, blur_depth, sparse_depth, target, acc, prop
             out = fast_plan.issue(guidance, blur_depth, sparse_depth, target, acc)
             if out is None:        # something the lean path does not handle (stream change, capture, ...): the general one
                 with torch.no_grad():
-                    out = forward_resident(guidance, blur_depth, sparse_depth, prop_time, fast_plan.blend, score=(target, acc), guard=0,
-                                           _plan=fast_plan.plan)
+                    out = forward_resident(guidance, blur_depth, sparse_depth, prop_time, fast_plan.blend, score=(target, acc),
+                                           _plan=fast_plan.plan if _RESIDENT_GUARD != "all" else None)
             return out.unsqueeze(1)
     dev = _require_device(guidance, blur_depth, sparse_depth, target)
     W0 = guidance.shape[-1]

@@ -235,7 +235,7 @@ def test_resident_timeout_is_repaired_in_place(c_oracle):
     with torch.no_grad():
         ref = multi_launch(xt.unsqueeze(1), gt, None, T, F.kres_plan(K, B, H, W, T)["steps_per_phase"], None)
         for form in (F.STEP_FMA, F.STEP_DOT2):
-            out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1, step_form=form)
+            out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1, step_form=form, guard=0)      # (the HOST repair: no device-side guard)
             torch.cuda.synchronize()
             assert bool(torch.isnan(out).any())
             n = F.resident_fallbacks()
@@ -430,6 +430,43 @@ def test_unet_ours_configuration_is_guarded_on_the_device(B, H, W, T, sparse, c_
                 got = step(lf, lb)
                 for a, b_, what in zip(got, want, ("refined depth", "dL/dx", "dL/dguided")):
                     assert bits_equal(a, b_, which="%s, time-out forced in %s" % (what, "forward" if lf else "sweep"))
+            F.ensure_resident_ok()
+    F.check_resident_errors()
+
+
+KGUARD = [(5, 24, 228, 304, 12, "f16", None), (5, 24, 228, 304, 12, "f16", torch.float32), (5, 3, 228, 304, 12, "f16", None),
+          (3, 4, 60, 72, 24, "f16", None), (5, 2, 40, 64, 9, "f32", None), (5, 1, 352, 1216, 12, "f16", None), (3, 2, 37, 40, 6, "f16", torch.float32)]
+
+
+@pytest.mark.parametrize("K,B,H,W,T,gd,state", KGUARD, ids=["%dx%dx%dx%dx%d_%s_%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "s32" if c[6] is not None else "s") for c in KGUARD])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_kxk_inference_is_guarded_on_the_device(K, B, H, W, T, gd, state, sparse, c_oracle):
+    """Round 5: every unscored K x K resident call carries the device-side guard (cspnk_resident_repair): all tiles are forced to
+    give up, and a GPU consumer behind the call sees the finished depth.  FMA step form: the bits of the multi-launch schedule
+    with the same phase length (the guard rounds the state where that kernel does); dot-product form (config 3's default):
+    within the fp16 tolerance of the configuration, like that form itself."""
+    import warnings
+    x, g_, s = inputs(c_oracle, B, H, W, K, sparse, seed=140)
+    tdt = torch.float16 if gd == "f16" else torch.float32
+    xt, gt, st = dev(x, tdt), dev(g_, tdt), dev(s, tdt)
+    sdt = tdt if state is None else state
+    x0 = xt[:, 0].to(sdt).contiguous()
+    sp = None if st is None else st[:, 0].to(sdt).contiguous()
+    rp = F.kres_plan(K, B, H, W, T, int(sparse), 0, 0, 0, F.CSPN_F16 if gd == "f16" else F.CSPN_F32)
+    assert rp is not None
+    ref = multi_launch(xt, gt, st, T, rp["steps_per_phase"], state)[:, 0]
+    forms = [F.STEP_FMA] + ([F.STEP_DOT2] if (K == 5 and gd == "f16" and state is None and rp["quads_per_thread"] == 1) else [])
+    with torch.no_grad(), resident("on"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for form in forms:
+            with _spin_limit(1):
+                out = F.pac_forward_resident(gt, x0, sp, T, step_form=form)
+            nan_seen = torch.isnan(out).any()
+            assert not bool(nan_seen), form
+            if form == F.STEP_FMA:
+                assert bits_equal(out, ref, which="K x K FMA form, guard-repaired")
+            else:
+                assert float((out.float() - ref.float()).abs().max()) <= 8e-3 * float(ref.float().abs().max())
             F.ensure_resident_ok()
     F.check_resident_errors()
 

@@ -517,6 +517,50 @@ def test_timed_out_result_is_complete_for_gpu_consumers(B, H, W, T, sparse, c_or
     F.check_resident_errors()
 
 
+@pytest.mark.parametrize("B,H,W", [(24, 228, 304), (3, 228, 304), (8, 352, 1216)], ids=["config2", "nyu_b3", "kitti_b8"])
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_scored_forward_under_guard_all(B, H, W, sparse, c_oracle):
+    """set_resident_guard("all"): the scored forward carries the guard too — for a host that hands forward_scored's refined depth
+    to other GPU work before it gathers the metrics.  Every tile gives up; the guard re-computes the depth (the multi-launch
+    schedule's bits) and adds the metric terms of exactly the pixels the failed launch left unscored: a reduction enqueued right
+    behind the call sees the finished depth, and the accumulated sums equal an undisturbed call's (to the summation order)."""
+    import warnings
+    from cspn_monodepth_amd import evaluation as ev
+    T = 24
+    g, d, s = c_oracle.synthetic_inputs(700 + B, B, H, W, 12, max(2, H * W // 140) if sparse else None)
+    tgt = np.maximum(d + 0.1 * c_oracle.hash_normal(701, 9, d.shape), 0.0).astype(np.float32)
+    tgt[c_oracle.hash_uniform(702, 9, d.shape) < 0.05] = 0.0
+    gt, dt, st, tt = dev(g), dev(d), dev(s), dev(tgt)
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with resident("off"):
+            acc0 = ev.new_accumulator(DEV)
+            ref = m.forward_scored(gt, dt, st, tt, acc0)
+        with resident("on"), guard("all"):
+            acc1 = ev.new_accumulator(DEV)
+            m.forward_scored(gt, dt, st, tt, acc1)              # a clean call first (registers the fast path)
+            acc1.zero_()
+            st_ = F._resident_state(gt.device)
+            for how in ("general path", "fast path"):
+                with spin_limit(1):                             # (a spin limit keeps the call on the general path ...)
+                    out = m.forward_scored(gt, dt, st, tt, acc1) if how == "general path" else None
+                if how == "fast path":                          # ... the fast path is forced to fail through its plan copy
+                    fp = [v for v in F._SCORED_FAST.values() if (v.B, v.H, v.W) == (B, H, W) and v.blend == int(sparse)][0]
+                    fp.plan_guarded.spin_limit = 1
+                    try:
+                        out = m.forward_scored(gt, dt, st, tt, acc1)
+                    finally:
+                        fp.plan_guarded.spin_limit = 0
+                total = out.double().sum()
+                assert float(total) == float(ref.double().sum()) and bits_equal(out, ref, T=T, sparse=sparse, which="scored, " + how)
+                assert not st_["journal"]                       # guarded: nothing journaled
+            assert np.allclose(acc1.sum(0).cpu().numpy(), 2 * acc0.sum(0).cpu().numpy(), rtol=1e-6)
+            F.ensure_resident_ok()
+            assert F.resident_fallbacks() >= 1
+    F.check_resident_errors()
+
+
 @pytest.mark.parametrize("name", golden_names("g1_") + golden_names("g2_"))
 def test_guard_recomputation_on_reference_goldens(name):
     """The guard's re-computation against the vectors captured from the reference (small / degenerate / NaN-spreading /
