@@ -291,6 +291,9 @@ __global__ __launch_bounds__(REP_THREADS) void cspnk_resident_repair(const KRepA
                         u = fmaf(w[c], cur[(ry + dy) * R + rx + dx], u);
                     }
                     if (BLEND) u = __fadd_rn(u, __fmul_rn(m, ldf<ST>(a.x0, pbase + p)));
+                    // (opaque: left to the compiler, the last FMA and the conversion fuse into ONE v_fma_mixlo_f16 — a single rounding of
+                    // the exact sum where cspnk_resident rounds twice, fp32 then half: 2e-4 of the pixels differed by a half ulp)
+                    asm volatile("" : "+v"(u));
                     if (round_now) u = round_to<ST>(u);
                 }
                 nxt[ry * R + rx] = u;

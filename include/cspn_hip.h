@@ -283,13 +283,18 @@ typedef struct cspn_resident_plan {
     unsigned long long* debug_stamps; /* in: developer probe, device buffer [workgroups][16] of 100 MHz wall-clock stamps
                                        * (start, weights derived, then per phase: staged, steps done, exchanged) or NULL */
     int step_form;          /* cspnk_forward_resident, in: CSPN_STEP_AUTO (0), CSPN_STEP_FMA or CSPN_STEP_DOT2 — see there */
-    int guard;              /* cspn3_forward_resident, in (ABI 10): != 0 enqueues a guard kernel behind the call's launch(es).  It reads
-                             * the call's abort word and returns at once unless a tile gave up (co-residency time-out); then it
-                             * re-computes the whole refined depth on the stream, with the resident kernel's arithmetic (bit-identical).
-                             * Whatever consumes `out` later on that stream — any GPU kernel, a copy to the host — sees the finished
-                             * tensor, as with the reference's ATen module (CSPN_new.py:80-92); the error words are still set, for the
-                             * host's statistics.  Plain inference calls only (no history, no scoring), T <= 54; refused otherwise.
-                             * Costs the success path one empty launch (~2 us on the stream). */
+    int guard;              /* in (ABI 10): != 0 enqueues a guard kernel behind the call's launch(es).  It reads the call's abort word and
+                             * returns at once unless a tile gave up (co-residency time-out); then it re-computes the whole result of the
+                             * call on the stream with the resident kernel's arithmetic.  Whatever consumes the result later on that
+                             * stream — any GPU kernel, a copy to the host — sees the finished tensor, as with the reference's ATen
+                             * module (CSPN_new.py:80-92); the error words are still set, for the host's statistics.
+                             * cspn3_forward_resident: every form — inference, scored inference (the guard also adds the metric terms of
+                             * the pixels the failed launch left unscored), training forward; cspn3_transposed_resident(_guidance);
+                             * the K = 3 fp32 softmax model through cspnk_forward_resident(_history): bit-identical results.
+                             * cspnk_forward_resident, unscored: the bits of the FMA step form; for the dot-product form the
+                             * half-precision recurrence with one FMA per tap (within that form's fp16 tolerance).
+                             * T * (K / 2) <= 54; refused where no form exists (K x K scored / fp16 training forms, cspnk_transposed_resident).
+                             * Costs the success path one small launch (~1-2 us on the stream). */
 } cspn_resident_plan;
 #define CSPN_STEP_AUTO 0   /* the dot-product form where it exists (K = 5, fp16 guidance, fp16 planes), else the FMA form  */
 #define CSPN_STEP_FMA 1    /* one v_fma_mix_f32 per tap, fp32 state inside a phase: the bits of the multi-launch schedule   */
