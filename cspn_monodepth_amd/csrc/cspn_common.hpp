@@ -46,6 +46,11 @@ int resident_repair_launch(const float* g, long bs, long cs, const float* d0, co
 bool kres_repair_fits(int K, int T);
 int kres_repair_launch(const void* g, int g_dtype, int K, const void* x0, const void* sparse, void* out, int state_dtype,
                        const unsigned* abort_word, unsigned seq, int B, int H, int W, int T, int round_every, int blend, int n_cu, void* stream);
+// ... and of the K = 5 fp16 training forms: cspnk_forward_resident_history's dot-product launch and cspnk_transposed_resident
+int kres_history_repair_launch(const void* g, const void* x0, const void* sparse, void* hist, void* wk_out, const unsigned* abort_word, unsigned seq,
+                               int B, int H, int W, int T, int blend, int n_cu, void* stream);
+int kres_sweep_repair_launch(const void* wk, const void* g_T, const void* sparse, int in_dtype, float* g32_out, float* hist, const unsigned* abort_word,
+                             unsigned seq, int B, int H, int W, int T, int premask, int n_cu, void* stream);
 // cspn_debug.hip: the poisoned-LDS debugging aid (include/cspn_hip.h: cspn_debug_set_lds_poison)
 extern int g_lds_poison_on;
 void lds_poison(hipStream_t st);

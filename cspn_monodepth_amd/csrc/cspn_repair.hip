@@ -309,6 +309,149 @@ __global__ __launch_bounds__(REP_THREADS) void cspnk_resident_repair(const KRepA
     }
 }
 
+
+// ---- the K = 5 fp16 training forms (BASELINE config 3's shape; round 5) ------------------------------------------------------------
+// Guard of cspnk_forward_resident_history's dot-product launch (cspnk_d2<HIST>): history [T,B,H,W] receives x_1 .. x_T, the state rounded
+// to the plane dtype after EVERY step, wk_out the softmax taps BEFORE the blend is folded in, in the Taps<__half> layout — the arithmetic
+// of cspn_pac_prepare + cspn_propagate (history) at one step per launch (one FMA per tap), i.e. what the multi-launch training path
+// stores; the dot-product kernel's own bits are within the fp16 tolerance of it, and the backward differentiates whichever history and
+// taps it is handed.
+struct KHistRepArgs {
+    const void* g; const void* x0; const void* sparse; void* hist; void* wk_out;
+    const unsigned* abort_word; unsigned seq;
+    int B, H, W, T, tiles_x, tiles_y;
+};
+
+template <int K, typename GT, typename ST, int BLEND>
+__global__ __launch_bounds__(REP_THREADS) void cspnk_history_repair(const KHistRepArgs a) {
+    if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) return;
+    constexpr int RK = K / 2, NT = K * K - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.T, HALO = T * RK, R = REP_TILE + 2 * HALO, H = a.H, W = a.W;
+    float* cur = lds;
+    float* nxt = lds + (size_t)R * R;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const size_t HW = (size_t)H * W, plane = (size_t)a.B * HW;
+    for (int t = blockIdx.x; t < a.B * tiles; t += gridDim.x) {
+        const int b = t / tiles, tr = t - b * tiles, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int ry0 = ty * REP_TILE - HALO, rx0 = tx * REP_TILE - HALO;
+        const size_t gbase = (size_t)b * NT * HW, pbase = (size_t)b * HW;
+        GT* const wkb = static_cast<GT*>(a.wk_out) + (size_t)b * Taps<GT>::image_elems(NT, HW);
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * R; i += REP_THREADS) {
+            const int ry = i / R, rx = i - ry * R, y = ry0 + ry, x = rx0 + rx;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            cur[i] = in ? ldf<ST>(a.x0, pbase + (size_t)y * W + x) : 0.f;
+            nxt[i] = 0.f;
+        }
+        __syncthreads();
+        for (int s = 1; s <= T; ++s) {
+            const int lo = s * RK, n = R - 2 * lo;
+            for (int i = threadIdx.x; i < n * n; i += REP_THREADS) {
+                const int ry = lo + i / n, rx = lo + i % n, y = ry0 + ry, x = rx0 + rx;
+                float u = 0.f;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const size_t p = (size_t)y * W + x;
+                    const bool own = ry >= HALO && ry < HALO + REP_TILE && rx >= HALO && rx < HALO + REP_TILE;
+                    float w[NT];
+                    float mx = -INFINITY, den = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) { w[c] = ldf<GT>(a.g, gbase + (size_t)c * HW + p); mx = fmaxf(mx, w[c]); }
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) { w[c] = softmax_exp<GT>(w[c] - mx); den += w[c]; }
+                    const float inv = reciprocal_refined(den);
+                    float m = 0.f;
+                    if (BLEND) m = sgnf(ldf<ST>(a.sparse, pbase + p));
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        w[c] = softmax_weight<GT>(w[c], inv);
+                        if (s == 1 && own) stf(wkb, Taps<GT>::idx(c, p, HW), w[c]);      // the published taps: before the fold
+                        if (BLEND) w[c] = round_to<GT>(w[c] * (1.f - m));
+                    }
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        const int lin = c < NT / 2 ? c : c + 1, dy = lin / K - RK, dx = lin % K - RK;
+                        u = fmaf(w[c], cur[(ry + dy) * R + rx + dx], u);
+                    }
+                    if (BLEND) u = __fadd_rn(u, __fmul_rn(m, ldf<ST>(a.x0, pbase + p)));
+                    asm volatile("" : "+v"(u));                  // (no fma + cvt fusion: cspnk_resident_repair has the note)
+                    u = round_to<ST>(u);
+                    if (own) stf(static_cast<ST*>(a.hist) + (size_t)(s - 1) * plane + pbase, p, u);
+                }
+                nxt[ry * R + rx] = u;
+            }
+            __syncthreads();
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+    }
+}
+
+// Guard of cspnk_transposed_resident: G_t = stencil^T((1-m) G_{t+1}) with the transposed taps w_{NT-1-j}[p + off_j] read from the forward's
+// tap volume (zero where p + off_j leaves the image), one FMA per tap in row-major tap order from 0, fp32 state; history [T,B,H,W] f32
+// receives G_{T-1} .. G_0 (the UNMASKED G_t; what travels is (1-m) G_t), g32_out — when given — G_T as fp32.  The arithmetic of
+// cspnk_resident<TRANS>, i.e. of cspn_transpose_weights + cspn_propagate (history, CSPN_BLEND_PREMASK), bit for bit.
+struct KSweepRepArgs {
+    const void* wk; const void* g_T; const void* sparse; float* g32_out; float* hist;
+    const unsigned* abort_word; unsigned seq;
+    int B, H, W, T, tiles_x, tiles_y;
+};
+
+template <int K, typename WT, typename INT, int PREMASK>
+__global__ __launch_bounds__(REP_THREADS) void cspnk_sweep_repair(const KSweepRepArgs a) {
+    if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) return;
+    constexpr int RK = K / 2, NT = K * K - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.T, HALO = T * RK, R = REP_TILE + 2 * HALO, H = a.H, W = a.W;
+    float* cur = lds;
+    float* nxt = lds + (size_t)R * R;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const size_t HW = (size_t)H * W, plane = (size_t)a.B * HW;
+    for (int t = blockIdx.x; t < a.B * tiles; t += gridDim.x) {
+        const int b = t / tiles, tr = t - b * tiles, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int ry0 = ty * REP_TILE - HALO, rx0 = tx * REP_TILE - HALO;
+        const size_t pbase = (size_t)b * HW;
+        const WT* const wkb = static_cast<const WT*>(a.wk) + (size_t)b * Taps<WT>::image_elems(NT, HW);
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * R; i += REP_THREADS) {
+            const int ry = i / R, rx = i - ry * R, y = ry0 + ry, x = rx0 + rx;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            float v = 0.f;
+            if (in) {
+                const size_t p = (size_t)y * W + x;
+                v = ldf<INT>(a.g_T, pbase + p);
+                if (a.g32_out && ry >= HALO && ry < HALO + REP_TILE && rx >= HALO && rx < HALO + REP_TILE) a.g32_out[pbase + p] = v;
+                if (PREMASK) v = __fmul_rn(v, 1.f - sgnf(ldf<INT>(a.sparse, pbase + p)));
+            }
+            cur[i] = v;
+            nxt[i] = 0.f;
+        }
+        __syncthreads();
+        for (int s = 1; s <= T; ++s) {
+            const int lo = s * RK, n = R - 2 * lo;
+            for (int i = threadIdx.x; i < n * n; i += REP_THREADS) {
+                const int ry = lo + i / n, rx = lo + i % n, y = ry0 + ry, x = rx0 + rx;
+                float u = 0.f;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const size_t p = (size_t)y * W + x;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        const int lin = c < NT / 2 ? c : c + 1, dy = lin / K - RK, dx = lin % K - RK;
+                        const int ys = y + dy, xs = x + dx;
+                        const bool tin = ys >= 0 && ys < H && xs >= 0 && xs < W;
+                        const float wt = tin ? ldf<WT>(wkb, Taps<WT>::idx(NT - 1 - c, (size_t)ys * W + xs, HW)) : 0.f;
+                        u = fmaf(wt, cur[(ry + dy) * R + rx + dx], u);
+                    }
+                    if (ry >= HALO && ry < HALO + REP_TILE && rx >= HALO && rx < HALO + REP_TILE) a.hist[(size_t)(s - 1) * plane + pbase + p] = u;
+                    if (PREMASK) u = __fmul_rn(1.f - sgnf(ldf<INT>(a.sparse, pbase + p)), u);
+                }
+                nxt[ry * R + rx] = u;
+            }
+            __syncthreads();
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+    }
+}
+
 }  // namespace
 
 namespace cspn_detail {
@@ -399,6 +542,46 @@ int kres_repair_launch(const void* g, int g_dtype, int K, const void* x0, const 
     }
     if (gh) return sh ? kres_repair_launch_t<5, __half, __half>(a, blend, lds, grid, st) : kres_repair_launch_t<5, __half, float>(a, blend, lds, grid, st);
     return kres_repair_launch_t<5, float, float>(a, blend, lds, grid, st);
+}
+
+template <typename KernT, typename ArgsT>
+static int guarded_launch(KernT kern, std::atomic<size_t>* granted, const ArgsT& a, size_t lds, int n_tiles, int n_cu, hipStream_t st) {
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (lds > 64 * 1024 && granted[dev & 63].load(std::memory_order_acquire) < lds) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted[dev & 63].store(lds, std::memory_order_release);
+    }
+    const int cap = n_cu >= 64 ? n_cu / 8 : 8;
+    hipLaunchKernelGGL(kern, dim3(n_tiles > cap ? cap : n_tiles), dim3(REP_THREADS), lds, st, a);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int kres_history_repair_launch(const void* g, const void* x0, const void* sparse, void* hist, void* wk_out, const unsigned* abort_word, unsigned seq,
+                               int B, int H, int W, int T, int blend, int n_cu, void* stream) {
+    if (!kres_repair_fits(5, T)) return fail("cspnk_forward_resident_history: the guard re-computes at most 27 steps of a 5 x 5 stencil (T=%d)", T);
+    KHistRepArgs a{g, x0, sparse, hist, wk_out, abort_word, seq, B, H, W, T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
+    const int R = REP_TILE + 4 * T;
+    static std::atomic<size_t> granted[2][64];
+    if (blend) return guarded_launch(cspnk_history_repair<5, __half, __half, 1>, granted[1], a, (size_t)2 * R * R * sizeof(float), B * a.tiles_x * a.tiles_y, n_cu, static_cast<hipStream_t>(stream));
+    return guarded_launch(cspnk_history_repair<5, __half, __half, 0>, granted[0], a, (size_t)2 * R * R * sizeof(float), B * a.tiles_x * a.tiles_y, n_cu, static_cast<hipStream_t>(stream));
+}
+
+int kres_sweep_repair_launch(const void* wk, const void* g_T, const void* sparse, int in_dtype, float* g32_out, float* hist, const unsigned* abort_word,
+                             unsigned seq, int B, int H, int W, int T, int premask, int n_cu, void* stream) {
+    if (!kres_repair_fits(5, T)) return fail("cspnk_transposed_resident: the guard re-computes at most 27 steps of a 5 x 5 stencil (T=%d)", T);
+    KSweepRepArgs a{wk, g_T, sparse, g32_out, hist, abort_word, seq, B, H, W, T, ceil_div(W, REP_TILE), ceil_div(H, REP_TILE)};
+    const int R = REP_TILE + 4 * T;
+    const size_t lds = (size_t)2 * R * R * sizeof(float);
+    const int n = B * a.tiles_x * a.tiles_y;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static std::atomic<size_t> granted[4][64];
+    if (in_dtype == CSPN_F16)
+        return premask ? guarded_launch(cspnk_sweep_repair<5, __half, __half, 1>, granted[0], a, lds, n, n_cu, st)
+                       : guarded_launch(cspnk_sweep_repair<5, __half, __half, 0>, granted[1], a, lds, n, n_cu, st);
+    return premask ? guarded_launch(cspnk_sweep_repair<5, __half, float, 1>, granted[2], a, lds, n, n_cu, st)
+                   : guarded_launch(cspnk_sweep_repair<5, __half, float, 0>, granted[3], a, lds, n, n_cu, st);
 }
 
 }  // namespace cspn_detail

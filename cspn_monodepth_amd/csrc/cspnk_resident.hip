@@ -58,12 +58,19 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
 
     const int tid = threadIdx.x;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int tile = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    // The reverse sweep takes the whole batch in ONE launch of a.rounds * (nb * tiles) workgroups: the first nb * tiles of them (round 0:
+    // images b0 .. b0 + nb - 1, one workgroup per CU) are resident at once, the workgroups of round r + 1 (images b0 + (r+1) nb ...) are
+    // dispatched in blockIdx order as those of round r finish — no second launch and no drain between the halves, and nothing carried
+    // from one image to the next in registers (a round LOOP inside the kernel, as cspnk_d2 has, costs this kernel 14-33 more spilled
+    // VGPRs: 97 us instead of 2 x 45).  Flags and exchange planes are per image: the rounds share nothing.
+    const int wg_round = TRANS ? a.nb * tiles_per_img : (int)gridDim.x;
+    const int round = TRANS ? (int)blockIdx.x / wg_round : 0;
+    const int tile = xcd_contiguous_id(TRANS ? (int)blockIdx.x - round * wg_round : (int)blockIdx.x, wg_round);
     const int bl = tile / tiles_per_img;
     const int trem = tile - bl * tiles_per_img;
     const int ty = trem / a.tiles_x;
     const int tx = trem - ty * a.tiles_x;
-    const int b = a.b0 + bl;
+    const int b = a.b0 + round * a.nb + bl;
     const int H = a.H, W = a.W;
     const int y0 = ty * a.th, x0 = tx * a.tw;
     const unsigned HW = (unsigned)(H * W);
@@ -84,6 +91,8 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
             }
         }
     };
+
+    if (TRANS && b >= a.B) { count_out(); return; }      // the last round of a ragged batch has fewer images
 
     // TRANS = 2: the cotangent and the sparse plane arrive as fp16 (the training step on half planes hands them over as they
     // are: no cast kernels); the state is fp32 all the same, and a.out, when set, receives G_T as fp32 for the backward tail
@@ -608,6 +617,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
 
 // ------------------------------------------------------------------------------------------------ host side
 constexpr int KRES_MAX_NO_K5 = 2;
+constexpr int KRES_T_MAX_ROUNDS = 8;    // rounds of the reverse sweep in one launch
+#ifndef CSPN_KT_ONE_LAUNCH
+#define CSPN_KT_ONE_LAUNCH 1
+#endif
 constexpr int KRES_MAX_NO_K3 = 4;
 
 struct KGeom {
@@ -918,7 +931,7 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
 int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_T, const void* sparse_f32, int in_dtype, float* g_T_f32_out,
                               float* history, void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int premask,
                               const cspn_resident_plan* plan, cspn_stream_t stream) {
-    if (plan && plan->guard) return fail("cspnk_transposed_resident: no guard form (the K = 3 fp32 model's sweep is cspn3_transposed_resident)");
+    if (plan && plan->guard && !cspn_detail::kres_repair_fits(5, T)) return fail("cspnk_transposed_resident: the guard re-computes at most 27 steps (T=%d)", T);
     if (!wk || !g_T || !history || !work || B <= 0 || H <= 0 || W <= 0 || T < 1) return fail("cspnk_transposed_resident: bad arguments");
     if (K != 5 || w_dtype != CSPN_F16) return fail("cspnk_transposed_resident: K = 5 with an fp16 tap volume (K=%d, dtype %d)", K, w_dtype);
     if (premask && !sparse_f32) return fail("cspnk_transposed_resident: premask needs sparse");
@@ -961,11 +974,16 @@ int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_
     a.dbg = rp.debug_stamps;
     const bool clean = kregions_inside_image(g, H, W, T);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
+    // ONE launch for the whole batch (KRES_T_MAX_ROUNDS rounds of images_per_launch images at most per launch: the bounded neighbour wait
+    // is sized for launches of a few hundred microseconds).  -DCSPN_KT_ONE_LAUNCH=0: one launch per round, the schedule up to round 4.
+    const int ipl = g.imgs_per_launch < B ? g.imgs_per_launch : B;
+    const int max_rounds = CSPN_KT_ONE_LAUNCH ? KRES_T_MAX_ROUNDS : 1;
+    for (int b0 = 0; b0 < B; b0 += ipl * max_rounds) {
         a.b0 = b0;
-        a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
-        a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
-        const int grid = a.nb * g.tiles_x * g.tiles_y;
+        a.nb = (B - b0) < ipl ? (B - b0) : ipl;
+        a.rounds = ceil_div(B - b0, ipl) < max_rounds ? ceil_div(B - b0, ipl) : max_rounds;
+        a.last_chunk = (b0 + ipl * max_rounds >= B) ? 1 : 0;
+        const int grid = a.rounds * a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
 #define KT_CASE(BL, CL, NTHR) \
         if (!ok && blend == BL && (int)clean == CL && g.threads == NTHR) \
@@ -976,14 +994,16 @@ int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_
 #undef KT_CASE
         if (!ok) return cspn_detail::last_error()[0] ? 0 : fail("cspnk_transposed_resident: no instance for %d threads", g.threads);
     }
+    // the guard: a sweep that gave up is re-computed on the stream before the tail can read its planes (cspn_repair.hip)
+    if (rp.guard) return cspn_detail::kres_sweep_repair_launch(wk, g_T, premask ? sparse_f32 : nullptr, in_dtype, g_T_f32_out, history, a.status, seq, B, H, W, T, blend, ncu, stream);
     return 1;
 }
 
 int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const void* x0, const void* sparse, void* history, void* wk_out,
                                    void* work, unsigned seq, unsigned* host_err, int B, int H, int W, int T, int blend,
                                    const cspn_resident_plan* plan, cspn_stream_t stream) {
-    if (plan && plan->guard && !(K == 3 && g_dtype == CSPN_F32))
-        return fail("cspnk_forward_resident_history: plan->guard exists for K = 3 with fp32 guidance only");
+    if (plan && plan->guard && !(K == 3 && g_dtype == CSPN_F32) && !(K == 5 && g_dtype == CSPN_F16 && cspn_detail::kres_repair_fits(5, T)))
+        return fail("cspnk_forward_resident_history: plan->guard exists for K = 3 with fp32 guidance and for K = 5 with fp16 guidance up to 27 steps");
     if (!guided || !x0 || !history || !wk_out || !work || B <= 0 || H <= 0 || W <= 0 || T < 1)
         return fail("cspnk_forward_resident_history: bad arguments");
     if (K == 5 && g_dtype == CSPN_F16) {
@@ -1030,7 +1050,10 @@ int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const
         a.nb = g.imgs_per_launch < B ? g.imgs_per_launch : B;
         a.rounds = ceil_div(B, a.nb);
         a.last_chunk = 1;
-        return cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, 2, kregions_inside_image(g, H, W, T) ? 1 : 0, stream);
+        if (!cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, 2, kregions_inside_image(g, H, W, T) ? 1 : 0, stream)) return 0;
+        // the guard: a forward that gave up gets its T planes and its tap volume re-computed on the stream (cspn_repair.hip)
+        if (rp.guard) return cspn_detail::kres_history_repair_launch(guided, x0, blend ? sparse : nullptr, history, wk_out, a.status, seq, B, H, W, T, blend ? 1 : 0, ncu, stream);
+        return 1;
     }
     if (K != 3 || g_dtype != CSPN_F32)
         return fail("cspnk_forward_resident_history: the training form exists for K = 3 with fp32 guidance and for K = 5 with fp16 guidance "

@@ -377,7 +377,8 @@ int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const
  * CSPN_F32, or CSPN_F16 — the training step on half planes hands its cotangent and sparse plane over as they are (no cast
  * launches); the state is fp32 either way, and g_T_f32_out [B,H,W], when given, receives G_T as fp32 for cspn_pac_backward_tail.
  * Workspace (cspnk_resident_workspace_bytes with CSPN_F32), seq, host_err (completion word included), plan: as
- * cspn3_transposed_resident. */
+ * cspn3_transposed_resident.  ONE launch for up to 8 x images_per_launch images: rounds x images_per_launch x tiles workgroups, the
+ * first round's resident at once, the later rounds' dispatched as those finish (a plan's debug_stamps buffer must hold that many rows). */
 int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_T, const void* sparse_or_null, int in_dtype,
                               float* g_T_f32_out_or_null, float* history, void* work, unsigned seq, unsigned* host_err_or_null,
                               int B, int H, int W, int T, int premask, const cspn_resident_plan* plan_or_null, cspn_stream_t stream);

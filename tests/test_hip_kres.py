@@ -614,3 +614,74 @@ def test_k5_resident_reverse_sweep_equals_the_streaming_one(B, H, W, T, sparse, 
     assert bits_equal(out, ref), float((out - ref).abs().max())
     assert g16.dtype == torch.float32 and bits_equal(g16, cot.half().float())
     assert bits_equal(out16, ref16), float((out16 - ref16).abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,T", [(24, 228, 304, 12), (3, 228, 304, 12), (2, 40, 64, 6), (25, 228, 304, 12), (1, 352, 1216, 12), (5, 60, 72, 7)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_k5_fp16_training_step_is_guarded_on_the_device(B, H, W, T, sparse, c_oracle):
+    """Round 5: the K = 5 fp16 training forms (config 3's shape) carry the device-side guard too.  Every tile is forced to give up
+    (one poll).  Reverse sweep (cspnk_transposed_resident — ONE launch for the whole batch now): all T planes of G and the fp32 copy
+    of G_T are the un-forced sweep's bits, fp32 and fp16 cotangents.  Forward with history (the dot-product kernel): the re-computed
+    tap volume is cspn_pac_prepare's and the re-computed history the multi-launch forward's at one step per launch, bit for bit (the
+    guard's arithmetic: one FMA per tap, the state rounded to half after every step).  A whole training step with both launches
+    forced neither raises nor leaves a NaN, and its gradients stay within the fp16 tolerances of the un-forced step's."""
+    import warnings
+    K = 5
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=190)
+    gt = dev(gd, torch.float16)
+    xt = dev(x, torch.float16)[:, 0].contiguous()
+    sp = dev(s, torch.float16)[:, 0].contiguous() if sparse else None
+    cot = dev(c_oracle.hash_normal(191, 9, (B, H, W)))
+    rp = F.kres_plan(K, B, H, W, T, int(sparse))
+    if rp is None or rp["quads_per_thread"] != 1:
+        pytest.skip("no one-oct tiling")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with torch.no_grad(), resident("on"):
+            wk0, _ = F.pac_prepare(gt)
+            n0 = F.resident_fallbacks()
+            for c_, sp_ in ((cot, None if sp is None else sp.float()), (cot.half(), sp)):
+                g_ok, want = F.pac_transposed_resident(wk0, c_, sp_, T)
+                with _spin_limit(1):
+                    g_rep, got = F.pac_transposed_resident(wk0, c_, sp_, T)
+                total = got.double().sum()              # a GPU consumer enqueued right behind the call
+                assert float(total) == float(want.double().sum()) or bool(torch.isnan(want).any())
+                assert bits_equal(got, want, which="K = 5 sweep, guard-repaired") and bits_equal(g_rep.float(), g_ok.float())
+            with resident("off"):
+                _, hist0 = F.propagate(wk0, xt, sp, K, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True,
+                                       plan=F.dtype_default_plan(K, wk0.dtype, dict(steps_per_launch=1)))
+            F.ensure_resident_ok()
+            multi_tile = rp["tiles_x"] * rp["tiles_y"] > 1 and T > rp["steps_per_phase"]      # (else: no exchange, nothing to wait for)
+            if multi_tile:
+                assert F.resident_fallbacks() > n0         # (the time-outs were real: counted, warned about, repaired on the device)
+            n1 = F.resident_fallbacks()
+            with _spin_limit(1):
+                out1, hist1, wk1 = F.pac_forward_resident_history(gt, xt, sp, T)
+            F.ensure_resident_ok()
+            if multi_tile:                                 # (a single tile has no neighbour to wait for: the dot-product kernel's own bits stand)
+                assert F.resident_fallbacks() > n1
+                assert bits_equal(wk1, wk0, which="K = 5 tap volume, guard-repaired")
+                assert bits_equal(hist1, hist0, which="K = 5 history, guard-repaired") and bits_equal(out1, hist0[T - 1])
+            else:
+                assert float((hist1.float() - hist0.float()).abs().max()) <= 4e-3 * float(hist0.float().abs().max())
+        if B * H * W > 3 * 228 * 304:
+            return
+        m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=None)
+        cot4 = cot.half().unsqueeze(1)
+
+        def step(lim):
+            xg, gg = dev(x, torch.float16).requires_grad_(True), gt.clone().requires_grad_(True)
+            with _spin_limit(lim):
+                o = m(xg, gg, sparse_depth=None if sp is None else sp.unsqueeze(1))
+                o.backward(cot4)
+            return o.detach().float(), xg.grad.float(), gg.grad.float()
+
+        with resident("on"):
+            want = step(0)
+            got = step(1)
+            F.ensure_resident_ok()
+        for a, b_, tol, what in zip(got, want, (8e-3, 1e-2, 3e-2), ("refined depth", "dL/dx", "dL/dguided")):
+            assert bool(torch.isfinite(a).all()), what
+            assert float((a - b_).abs().max()) <= tol * float(b_.abs().max()), what
+    F.check_resident_errors()

@@ -97,4 +97,42 @@ for case in range(max(20, n_cases // 3)):
     if not torch.equal(out, ref):
         kbad += 1
         print("K x K MISMATCH case %d: K=%d B=%d H=%d W=%d T=%d sparse=%s f32=%s: %d px" % (case, K, B, H, W, T, sparse, f32, int((out != ref).sum())), flush=True)
+# K = 5 fp16 training forms: the reverse sweep (forced against un-forced, bit for bit) and the forward with history (against
+# cspn_pac_prepare + one-step launches, bit for bit, whenever a tile really gave up)
+tbad = tdone = 0
+for case in range(max(20, n_cases // 3)):
+    B = int(rng.integers(1, 30)); H = int(rng.integers(6, 120)); W = int(8 * rng.integers(1, 40)); T = int(rng.integers(2, 20))
+    sparse = bool(rng.random() < 0.5)
+    rp = F.kres_plan(5, B, H, W, T, int(sparse))
+    if rp is None or rp["quads_per_thread"] != 1 or 2 * T > 54:
+        continue
+    gd = c_oracle.hash_normal(7000 + case, 1, (B, 24, H, W)); x = c_oracle.hash_uniform(7000 + case, 2, (B, 1, H, W), 0.0, 10.0)
+    s = c_oracle.hash_sparse(7000 + case, 3, x, 0.02) if sparse else None
+    gt, xt = dev(gd, torch.float16), dev(x, torch.float16)[:, 0].contiguous()
+    st = None if s is None else dev(s, torch.float16)[:, 0].contiguous()
+    cot = dev(c_oracle.hash_normal(7000 + case, 9, (B, H, W))).half()
+    F.set_resident("on"); F.set_resident_guard(True)
+    with torch.no_grad():
+        wk0, _ = F.pac_prepare(gt)
+        g0, want = F.pac_transposed_resident(wk0, cot, st, T)
+        g1, got = forced(lambda: F.pac_transposed_resident(wk0, cot, st, T))
+        ok = torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0)) and torch.equal(g0, g1)
+        F.ensure_resident_ok()                            # (the sweep's time-out is counted where the host next looks: look now)
+        n0 = F.resident_fallbacks()
+        out1, hist1, wk1 = forced(lambda: F.pac_forward_resident_history(gt, xt, st, T))
+        F.ensure_resident_ok()
+        if F.resident_fallbacks() > n0:
+            F.set_resident("off")
+            try:
+                _, hist0 = F.propagate(wk0, xt, st, 5, T, F.BLEND_SPARSE if sparse else F.BLEND_NONE, keep_history=True,
+                                       plan=F.dtype_default_plan(5, wk0.dtype, dict(steps_per_launch=1)))
+                ok = ok and torch.equal(wk1, wk0) and torch.equal(torch.nan_to_num(hist1.float(), 7.0), torch.nan_to_num(hist0.float(), 7.0))
+            except RuntimeError:
+                pass
+            F.set_resident("on")
+    tdone += 1
+    if not ok:
+        tbad += 1
+        print("K = 5 TRAINING MISMATCH case %d: B=%d H=%d W=%d T=%d sparse=%s" % (case, B, H, W, T, sparse), flush=True)
+print("guard fuzz, K = 5 fp16 training forms: %d cases, %d mismatches" % (tdone, tbad))
 print("guard fuzz: %d 3x3 cases (%d with a forced time-out), %d mismatches; %d K x K cases, %d mismatches" % (done, timed_out, bad, kdone, kbad))
