@@ -163,19 +163,25 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
 
     const int tid = threadIdx.x;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int tile = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int bl = tile / tiles_per_img;                 // image within this launch
+    // A launch may hold several ROUNDS of nb images (-DCSPN_RES_ONE_LAUNCH=1; by default a launch is one round): rounds x (nb x tiles)
+    // workgroups, round 0's — images b0 .. b0 + nb - 1, at most one workgroup per CU — resident at once, those of round r + 1 dispatched
+    // in blockIdx order as round r's finish.  Flags and exchange planes are per image, so the rounds share nothing.  (cspnk_resident's
+    // reverse sweep runs that way: cspnk_resident.hip.)
+    const int wg_round = a.nb * tiles_per_img;
+    const int round = (int)blockIdx.x / wg_round;
+    const int tile = xcd_contiguous_id((int)blockIdx.x - round * wg_round, wg_round);
+    const int bl = tile / tiles_per_img;                 // image within this round
     const int trem = tile - bl * tiles_per_img;
     const int ty = trem / a.tiles_x;
     const int tx = trem - ty * a.tiles_x;
-    const int b = a.b0 + bl;
+    const int b = a.b0 + round * a.nb + bl;
     const int H = a.H, W = a.W;
     const int y0 = ty * a.th, x0 = tx * a.tw;
     const size_t HW = (size_t)H * W;
     const size_t plane = (size_t)a.B * HW;
     if (tid == 0) wg_bad = 0;
     int n_stamp = 0;
-    auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
+    auto stamp = [&]() { if (a.dbg && tid == 0 && round == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };   // (round 0's workgroups: [nb x tiles][16])
     stamp();
     // Completion word: every workgroup counts itself out (status word 2); the last one re-arms the counter for the next
     // launch — launches on a workspace never overlap — and, in the last launch of a call, stores `seq` to the second host
@@ -194,6 +200,8 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
             }
         }
     };
+
+    if (b >= a.B) { count_out(); return; }               // the last round of a ragged batch has fewer images
 
     const float* __restrict__ din0 = uniform_ptr(a.d0 + (size_t)b * HW);
     const float* __restrict__ spg = BLEND ? uniform_ptr(a.sparse + (size_t)b * HW) : nullptr;
@@ -843,6 +851,15 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
 // ------------------------------------------------------------------------------------------------ host side
 constexpr int RES_MAX_NQ = 5;
 
+constexpr int RES_MAX_ROUNDS = 8;       // rounds of images_per_launch images in one launch (-DCSPN_RES_ONE_LAUNCH=1)
+// Rounds in one launch: measured, NOT the default (same box, three alternating passes, profiles/r05_rounds_ab.txt): KITTI B = 8 (2 rounds of
+// 4 images on 256 workgroups) 92.4-93.4 us per scored forward against 92.2-93.7 with one launch per round, NYU B = 48 91.7-92.1 against
+// 90.4-90.9 (slower), only a ragged third round gains (KITTI B = 9: 121-123 against 126-127).  A round-1 workgroup starts when a CU is freed,
+// but its neighbours start as scattered as round 0's workgroups finish: the neighbour waits pay what the drain and the launch gap cost.
+// The K = 5 reverse sweep (cspnk_resident.hip) does gain (2 x 45.7 + gap -> 88.5 us) and runs its rounds in one launch.
+#ifndef CSPN_RES_ONE_LAUNCH
+#define CSPN_RES_ONE_LAUNCH 0
+#endif
 struct ResGeom {
     int S, tiles_x, tiles_y, tw, th, nq, wq, wr, hxw, hyw, dr, ls;
     int imgs_per_launch, launches;
@@ -1166,11 +1183,15 @@ int resident_launch(const void* guidance, long bs, long cs, const void* d0, cons
     if (rp.guard && ((mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 7 && mode != 4 && mode != 6) || ((mode == 0 || mode == 1 || mode == 4) && !out) ||
                      !cspn_detail::resident_repair_fits(T)))
         return fail("cspn3_forward_resident: plan->guard serves inference (plain / scored), the training forward and the reverse sweeps, T <= 54 steps");
-    for (int b0 = 0; b0 < B; b0 += g.imgs_per_launch) {
+    // one launch per round of images_per_launch images (-DCSPN_RES_ONE_LAUNCH=1: per RES_MAX_ROUNDS rounds — measured, not faster: see there)
+    const int ipl = g.imgs_per_launch < B ? g.imgs_per_launch : B;
+    const int max_rounds = CSPN_RES_ONE_LAUNCH ? RES_MAX_ROUNDS : 1;
+    for (int b0 = 0; b0 < B; b0 += ipl * max_rounds) {
         a.b0 = b0;
-        a.nb = (B - b0) < g.imgs_per_launch ? (B - b0) : g.imgs_per_launch;
-        a.last_chunk = (b0 + g.imgs_per_launch >= B) ? 1 : 0;
-        const int grid = a.nb * g.tiles_x * g.tiles_y;
+        a.nb = (B - b0) < ipl ? (B - b0) : ipl;
+        const int rounds = ceil_div(B - b0, ipl) < max_rounds ? ceil_div(B - b0, ipl) : max_rounds;
+        a.last_chunk = (b0 + ipl * max_rounds >= B) ? 1 : 0;
+        const int grid = rounds * a.nb * g.tiles_x * g.tiles_y;
         int ok = 0;
         if (g.threads == 1024) {
             ok = clean ? launch_resident_1024<1>(a, grid, g.lds_bytes, blend, mode, st) : launch_resident_1024<0>(a, grid, g.lds_bytes, blend, mode, st);

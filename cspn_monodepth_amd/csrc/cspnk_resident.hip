@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
     const size_t plane = (size_t)a.B * HW;
     if (tid == 0) wg_bad = 0;
     int n_stamp = 0;
-    auto stamp = [&]() { if (a.dbg && tid == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };
+    auto stamp = [&]() { if (a.dbg && tid == 0 && round == 0 && n_stamp < 16) a.dbg[(size_t)blockIdx.x * 16 + n_stamp++] = wall_clock64(); };   // (round 0's workgroups: [nb x tiles][16])
     stamp();
     // (no completion word for the inference launches: their results are checked where the host synchronises — functional.
     // ensure_resident_ok; the reverse sweep reports like cspn3_resident's training forms do: the last workgroup to count itself

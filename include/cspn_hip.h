@@ -246,8 +246,9 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * through two scratch planes (device-scope stores/loads + one phase flag per tile).  Results are bit-identical to
  * cspn3_propagate_from_guidance.  fp32, W % 4 == 0 (W_valid for narrower images), 16-byte aligned tensors.
  *
- * Co-residency: the workgroups of a launch wait for each other, so a launch never has more workgroups than the device
- * has CUs (cspn3_resident_plan chunks the batch).  The device must not be shared with ANOTHER resident launch at the
+ * Co-residency: the workgroups that refine one image wait for each other, so at most images_per_launch whole images — never more
+ * workgroups than the device has CUs — are in flight at a time (cspn3_resident_plan chunks the batch into `launches` launches of
+ * images_per_launch images).  The device must not be shared with ANOTHER resident launch at the
  * same time (a second process on the GPU, or a second stream of this process): callers serialise resident launches per
  * device (cspn_monodepth_amd/functional.py chains them with events).  The neighbour wait is bounded (seconds): on
  * time-out the launch stores 1 to status word 1 of the workspace (and to host_err[0], if given),
@@ -276,11 +277,11 @@ typedef struct cspn_resident_plan {
     int tile_w, tile_h;
     int quads_per_thread, threads;   /* threads, cspn3_*: in 0 / 512 = 512-thread workgroups (all forms), 1024 = one quad per thread on 1024
                                       * threads, four wavefronts per SIMD (inference forms only; small shards, round 5); out: the value used */
-    int images_per_launch, launches;
+    int images_per_launch, launches;   /* images in flight at a time; launches of that many images (the K = 5 reverse sweep: rounds of ONE launch) */
     int lds_bytes, n_cu;
     float region_over_tile; /* (tile + halo) area / tile area: the redundant-compute factor of the phases  */
     unsigned spin_limit;    /* in: polls before a neighbour wait gives up; 0 = default (~seconds)          */
-    unsigned long long* debug_stamps; /* in: developer probe, device buffer [workgroups][16] of 100 MHz wall-clock stamps
+    unsigned long long* debug_stamps; /* in: developer probe, device buffer [images_per_launch x tiles][16] of 100 MHz wall-clock stamps (round 0)
                                        * (start, weights derived, then per phase: staged, steps done, exchanged) or NULL */
     int step_form;          /* cspnk_forward_resident, in: CSPN_STEP_AUTO (0), CSPN_STEP_FMA or CSPN_STEP_DOT2 — see there */
     int guard;              /* in (ABI 10): != 0 enqueues a guard kernel behind the call's launch(es).  It reads the call's abort word and
@@ -293,7 +294,10 @@ typedef struct cspn_resident_plan {
                              * the K = 3 fp32 softmax model through cspnk_forward_resident(_history): bit-identical results.
                              * cspnk_forward_resident, unscored: the bits of the FMA step form; for the dot-product form the
                              * half-precision recurrence with one FMA per tap (within that form's fp16 tolerance).
-                             * T * (K / 2) <= 54; refused where no form exists (K x K scored / fp16 training forms, cspnk_transposed_resident).
+                             * cspnk_forward_resident_history, K = 5 fp16 (the dot-product kernel): history and tap volume re-computed as
+                             * cspn_pac_prepare + cspn_propagate (history) at one step per launch store them, bit for bit (the
+                             * dot-product kernel's own bits are within fp16 rounding of those); cspnk_transposed_resident: bit-identical.
+                             * T * (K / 2) <= 54; refused where no form exists (K x K scored inference).
                              * Costs the success path one small launch (~1-2 us on the stream). */
 } cspn_resident_plan;
 #define CSPN_STEP_AUTO 0   /* the dot-product form where it exists (K = 5, fp16 guidance, fp16 planes), else the FMA form  */
@@ -378,7 +382,7 @@ int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const
  * launches); the state is fp32 either way, and g_T_f32_out [B,H,W], when given, receives G_T as fp32 for cspn_pac_backward_tail.
  * Workspace (cspnk_resident_workspace_bytes with CSPN_F32), seq, host_err (completion word included), plan: as
  * cspn3_transposed_resident.  ONE launch for up to 8 x images_per_launch images: rounds x images_per_launch x tiles workgroups, the
- * first round's resident at once, the later rounds' dispatched as those finish (a plan's debug_stamps buffer must hold that many rows). */
+ * first round's resident at once, the later rounds' dispatched as those finish (debug_stamps: round 0's workgroups only). */
 int cspnk_transposed_resident(const void* wk, int w_dtype, int K, const void* g_T, const void* sparse_or_null, int in_dtype,
                               float* g_T_f32_out_or_null, float* history, void* work, unsigned seq, unsigned* host_err_or_null,
                               int B, int H, int W, int T, int premask, const cspn_resident_plan* plan_or_null, cspn_stream_t stream);
