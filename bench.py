@@ -910,12 +910,13 @@ def main():
             out = module(gt, dt_, s) if K == 3 else module(dt_, gt, s)
             out.backward(cot.to(out.dtype))
 
-        # (10 untimed + >= 30 timed passes.  The leg is launch-rate-bound — ~215 us of host time per pass, 150 of it the autograd
-        #  engine's — so it reads what the host threads' placement allows: see bind_cpus)
+        # (10 untimed + >= 100 timed passes; 30 until late in round 5: the pipeline fill and the closing synchronize were ~3 % of them.
+        #  Since round 5 the step is GPU-bound at configs 2 / 3 — lean host path, device-side guard: no host wait at the end of backward —
+        #  and host-bound, hence placement-sensitive, at shard sizes: see bind_cpus)
         for _ in range(10):
             fwd_bwd()
         torch.cuda.synchronize()
-        nt = max(30, args.steps // 8)
+        nt = max(100, args.steps // 2)
         t0t = time.perf_counter()
         for _ in range(nt):
             fwd_bwd()
