@@ -683,12 +683,20 @@ def test_contended_device_results_equal_uncontended(c_oracle):
 
 
 @pytest.mark.parametrize("where", ["forward", "reverse_sweep"])
-def test_timeout_in_a_training_step_raises_before_backward_returns(where, c_oracle):
-    """WITHOUT the device-side guard (set_resident_guard(False); also what the K x K training forms rely on): a training forward
+@pytest.mark.parametrize("model", ["3x3", "k5_fp16"])
+def test_timeout_in_a_training_step_raises_before_backward_returns(where, model, c_oracle):
+    """WITHOUT the device-side guard (set_resident_guard(False), or a call beyond the guard's 54 halo pixels): a training forward
     (history kept) or the backward's reverse sweep that timed out must raise before `.backward()` returns — i.e. before any
-    optimiser step could apply the gradients (functional._check_resident_at_end_of_backward)."""
+    optimiser step could apply the gradients (functional._check_resident_at_end_of_backward).  The 3x3 model and the K = 5 fp16
+    forms of config 3's shape (cspnk_forward_resident_history on the dot-product kernel, cspnk_transposed_resident)."""
     gt, dt, _ = _config2(c_oracle, seed=311, B=3)
     m = pkg.CSPN_new.AffinityPropagate(24, 3)
+    if model == "k5_fp16":
+        B, _, H, W = dt.shape
+        gt = dev(c_oracle.hash_normal(312, 1, (B, 24, H, W))).half()
+        dt = dt.half()
+        m5 = pkg.CSPN_ours.AffinityPropagate(12, state_dtype=None)
+        m = lambda g, d, s: m5(d, g, sparse_depth=s)      # noqa: E731
     with resident("on"), guard(False):
         for broken in (True, False):
             g_ = gt.clone().requires_grad_(True)
