@@ -1107,7 +1107,7 @@ def transposed_resident_guidance(guidance, S, g_T, sparse_f32, T, valid_w=0, _pl
     return ghist
 
 
-def pac_transposed_resident(wk, g_T, sparse, T):
+def pac_transposed_resident(wk, g_T, sparse, T, debug_stamps=None):
     """K = 5 reverse sweep on the forward's fp16 tap volume as weight-resident launches.  Returns (G_T as fp32 [B,H,W], ghist
     [T,B,H,W] f32 = G_{T-1} .. G_0).  The transposed taps are gathered once per launch and stay packed in registers; no
     transposed copy of the volume.  g_T / sparse: both fp32, or both fp16 (the kernel converts where it stages them and writes
@@ -1123,6 +1123,11 @@ def pac_transposed_resident(wk, g_T, sparse, T):
     premask = int(sparse is not None)
     guard = int(bool(_RESIDENT_GUARD) and 2 * int(T) <= _GUARD_MAX_T)
     rp = _with_spin_limit(_kres_plan_cached(5, B, H, W, int(T), premask, dev, 0, CSPN_F16)[1], guard=guard)
+    if debug_stamps is not None and rp is not None:     # developer probe: in-kernel time stamps of round 0's workgroups [images_per_launch x tiles][16]
+        c2 = _lib.cspn_resident_plan()
+        ctypes.memmove(ctypes.byref(c2), ctypes.byref(rp), ctypes.sizeof(c2))
+        c2.debug_stamps = debug_stamps.data_ptr()
+        rp = c2
 
     def launch(work, seq, host_err_ptr, stream_ptr):
         return L.cspnk_transposed_resident(_p(wk), CSPN_F16, 5, _p(g_T), _p(sparse), _dt(g_T), _p(g32) if half_in else None, _p(ghist),
