@@ -509,6 +509,22 @@ def propagate_from_guidance(guidance, d0, sparse, T, blend, keep_history=False, 
 # cspn3_forward_resident (include/cspn_hip.h): ONE launch per chunk of whole images, weights resident in registers for
 # all T steps, tile borders exchanged between co-resident workgroups.  Its launches must not overlap on a device, so
 # this module serialises them: a lock around (order after the previous resident launch's stream, launch), per device.
+#
+# Reader's map of the host protocol below (it is the largest part of this file; each piece has one job):
+#   _resident_state(dev)      per-device dict: launch lock, workspaces per shape, sequence number, the pinned error /
+#                             completion words the kernels write (host_err), the journal
+#   _resident_launch(...)     the ONE place a resident C entry is called from: error word looked at first (-> _recover),
+#                             workspace, stream ordering, sequence number, then either `guarded` (count only) or a journal entry
+#   guard (plan.guard)        device side, csrc/cspn_repair.hip: a timed-out call is re-computed on the stream before anything can
+#                             read it — every unscored call; such launches leave NO host state behind
+#   _JournalEntry / _journal_add / _recover    host side, for what carries no guard (the scored forward by default, anything with
+#                             set_resident_guard(False)): weak references to a call's tensors + how to redo it; _recover re-runs
+#                             exactly the entries whose output holds the poison pattern, or raises for training forms
+#   ensure_resident_ok / check_resident_errors / _check_resident_at_end_of_backward / _ResidentCheckpoint
+#                             the host-side touch-points where the error word is looked at (metric gather, graph replays, the
+#                             end of an UNGUARDED backward pass)
+#   forward_resident, transposed_resident(_guidance), pac_forward_resident(_history), pac_transposed_resident
+#                             one thin function per C entry: plan + guard decision, the launch closure, _resident_launch
 _RESIDENT_MODE = os.environ.get("CSPN_RESIDENT", "auto")      # "auto" | "on" | "off"
 _RES = {}                 # device index -> state dict (each with its OWN launch lock: devices never serialise each other)
 _RES_NEW_LOCK = threading.Lock()      # guards the creation of a device's state only
@@ -545,9 +561,9 @@ _RES_SEQ_MAX = (1 << 31) - 4096
 _RESIDENT_SPIN_LIMIT = 0   # test hook: polls before a neighbour wait gives up (0 = the engine's default, ~seconds)
 # The guard (include/cspn_hip.h: cspn_resident_plan.guard): plain inference calls — whose result goes to a consumer this package
 # does not know (a loss, a .cpu(), an image writer) — carry a device-side repair behind the resident launch, so that a timed-out
-# launch is re-computed ON THE STREAM before anything can read it.  The scored calls (consumer = this package's metric gather,
-# which repairs on the host first) and the training forms do not.  Costs one empty launch (~2 us); CSPN_RESIDENT_GUARD=0 or
-# set_resident_guard(False) for A/B runs.
+# launch is re-computed ON THE STREAM before anything can read it; so do the training forms (3x3, unet_ours, K = 5 fp16: no host
+# wait at the end of backward).  The scored calls (consumer = this package's metric gather, which repairs on the host first) do
+# not by default.  Costs one empty launch (~2 us); CSPN_RESIDENT_GUARD=0 or set_resident_guard(False) for A/B runs.
 # "all" (CSPN_RESIDENT_GUARD=all): the scored forward carries the guard as well (its re-computation also adds the metric terms of
 # the pixels the failed launch left unscored) — for a host that hands the refined depth of forward_scored to other GPU work before it
 # gathers the metrics; it costs the headline path the same 1-2 us per call, which is why it is not the default.
