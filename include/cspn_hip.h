@@ -254,9 +254,11 @@ int cspn_pac_out_size(int H, int W, const cspn_conv_geometry* geom, int* Ho, int
  * time-out the launch stores 1 to status word 1 of the workspace (and to host_err[0], if given),
  * drains, and leaves `out` incomplete — the tiles that gave up are filled with NaN (in `out`, or in the last history
  * plane) — and the caller must look at the word before trusting the result and re-run the call on the streaming entries
- * (cspn3_propagate_from_guidance: the same bits) when it is set.  cspn_monodepth_amd/functional.py does that for its callers:
- * inference calls are journaled and repaired in place at the next launch or host-side consumer (ensure_resident_ok),
- * training-form calls raise ResidentLaunchTimeout before `.backward()` returns, and after three time-outs the resident
+ * (cspn3_propagate_from_guidance: the same bits) when it is set — or set plan->guard (below, ABI 10) and let the library
+ * re-compute a call that gave up on the stream, before anything can read it.  cspn_monodepth_amd/functional.py does both for its
+ * callers: every unscored call (inference and training forms) carries the guard; calls without it (the scored forward by
+ * default) are journaled and repaired in place at the next launch or host-side consumer (ensure_resident_ok), unguarded
+ * training-form calls raise ResidentLaunchTimeout before `.backward()` returns; after three time-outs the resident
  * schedule switches itself off for the process.
  *
  * host_err_or_null: TWO host-mapped 32-bit words (pinned host memory the device can write): [0] receives 1 on a time-out;
