@@ -182,6 +182,10 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
                         for (int j = 0; j < 8; ++j) a.w_out[((size_t)b * 8 + j) * HW + (size_t)y * W + x] = 0.f;
                     }
                 }
+                // row padding inside the last valid quad: the resident launch stores (and, giving up, poisons) that quad as a whole, with
+                // zeros in its padding columns — a C-API reader of the repaired history plane must find them again
+                if (HIST && y >= 0 && y < H && x >= Wv && x < W && (x & ~3) < Wv && ry >= T && ry < T + REP_TILE && rx >= T && rx < T + REP_TILE)
+                    hp[(size_t)y * W + x] = 0.f;
                 nxt[ry * R + rx] = keep;
             }
             __syncthreads();
@@ -195,6 +199,8 @@ __global__ __launch_bounds__(REP_THREADS) void cspn3_resident_repair(const RepAr
                     const float v = cur[(T + ly) * R + T + lx];
                     if (SCORE && __float_as_uint(ob[(size_t)y * W + x]) == CSPN_POISON_F32) metric_terms(v, a.target[b * HW + (size_t)y * W + x], mf);
                     ob[(size_t)y * W + x] = v;
+                } else if (y < H && x < W && (x & ~3) < Wv) {
+                    ob[(size_t)y * W + x] = 0.f;      // padding columns of the last valid quad: zeros, as the clean launch stores them
                 }
             }
         }

@@ -663,6 +663,22 @@ class _WeakT(object):
         return None if base is None else torch.as_strided(base, self.size, self.stride, self.off)
 
 
+_NO_VERSION = object()      # an inference tensor: no version counter to compare
+
+
+def _tensor_version(t):
+    """t._version, or _NO_VERSION for tensors made under torch.inference_mode() (reading their counter raises; ADVICE r5: every
+    unguarded launch — the default scored forward among them — builds a journal entry, so eval under inference_mode crashed AFTER
+    the kernel had been enqueued).  Such an input cannot be checked for in-place modification: the repair trusts it, as it must
+    trust any tensor whose storage was rewritten through another view."""
+    if t is None:
+        return None
+    try:
+        return t._version
+    except RuntimeError:
+        return _NO_VERSION
+
+
 class _JournalEntry(object):
     """One resident launch that may still turn out to have timed out.  redo(out, *inputs): re-runs the call on the multi-launch
     schedule into `out` (None: a training-form launch / anything that cannot be repaired after the fact); out: the tensor a
@@ -675,13 +691,18 @@ class _JournalEntry(object):
 
     def __init__(self, redo, out=None, inputs=(), what="resident launch", nbytes=None):
         self.redo, self.out, self.what, self.weak = redo, out, what, False
-        self.inputs = tuple(inputs)
-        self.versions = tuple(None if t is None else t._version for t in self.inputs)
+        # a launch that cannot be repaired after the fact (redo None: the training forms) needs no inputs, and holds its output —
+        # the plane a tile that gave up poisons — weakly from the start: such an entry pins nothing of the caller's
+        self.inputs = tuple(inputs) if redo is not None else ()
+        self.versions = tuple(_tensor_version(t) for t in self.inputs)
         self.nbytes = nbytes if nbytes is not None else (
             sum(t.numel() * t.element_size() for t in self.inputs if t is not None) + (0 if out is None else out.numel() * out.element_size()))
+        if redo is None:
+            self.nbytes = 0
+            self.demote()
 
     def demote(self):
-        if not self.weak and self.redo is not None:
+        if not self.weak:
             self.out = None if self.out is None else _WeakT(self.out)
             self.inputs = tuple(None if t is None else _WeakT(t) for t in self.inputs)
             self.weak = True
@@ -698,7 +719,7 @@ class _JournalEntry(object):
         return out, ins
 
     def untouched(self, ins):
-        return all(t is None or t._version == v for t, v in zip(ins, self.versions))
+        return all(t is None or v is _NO_VERSION or _tensor_version(t) == v for t, v in zip(ins, self.versions))
 
 
 def _recover(dev, st):
@@ -719,16 +740,22 @@ def _recover(dev, st):
         lost, st["lost"] = st["lost"], False
         st.setdefault("mark_pool", []).extend(ev for _, ev in st.get("marks", []))
         st["marks"] = []
-        training = any(e.redo is None for e in journal)
-        _note_fallback(training=training)
         stale = []
+        training = False
         # launches that carried their own guard (cspn_resident_plan.guard) left no entry: if it was one of them, its guard kernel has
         # re-computed the result on the stream already
         repaired, st["guarded_pending"] = st.get("guarded_pending", 0), 0
         with _device_guard(dev):
             for e in journal:
                 if e.redo is None:
-                    continue                       # a training-form launch: raised below
+                    # an unguarded training-form launch: decided per entry, as the inference entries are (one CLEAN
+                    # training entry in the journal turned a guarded — already repaired — time-out of another launch into a raise).
+                    # Its `out` is the plane a tile that gave up poisons (d_T / G_0); dropped by the caller = nobody can read it;
+                    # never recorded = cannot tell, so it counts as failed.
+                    tout = e.out.get() if isinstance(e.out, _WeakT) else e.out
+                    if (e.out is None) or (tout is not None and _holds_poison(tout)):
+                        training = True
+                    continue
                 out, ins = e.resolve()
                 if out is None or not _holds_poison(out):
                     continue                       # finished cleanly — or the caller dropped the result: nobody can read it
@@ -740,6 +767,7 @@ def _recover(dev, st):
                     continue
                 e.redo(out, *ins)
                 repaired += 1
+        _note_fallback(training=training)
         # (nothing repaired and nothing wrong with the journal: the failed call's result was dropped by its caller, or its guard
         #  kernel has dealt with it — the event is counted and warned about, there is nothing to raise)
         if lost or training or stale:
@@ -1095,7 +1123,7 @@ def transposed_resident(w8, g_T, sparse_f32, T, valid_w=0):
                                            int(valid_w), int(T), int(sparse_f32 is not None),
                                            None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True, guarded=bool(guard))
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True, guarded=bool(guard), out=ghist[int(T) - 1])
     _lib.check(ok, "cspn3_transposed_resident")
     return ghist
 
@@ -1118,7 +1146,7 @@ def transposed_resident_guidance(guidance, S, g_T, sparse_f32, T, valid_w=0, _pl
                                                     _p(ghist), _p(work), seq, host_err_ptr, B, H, W, int(valid_w), int(T),
                                                     int(sparse_f32 is not None), None if rp is None else ctypes.byref(rp), stream_ptr)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True, guarded=bool(guard))
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=True, guarded=bool(guard), out=ghist[int(T) - 1])
     _lib.check(ok, "cspn3_transposed_resident_guidance")
     return ghist
 
@@ -1151,7 +1179,8 @@ def pac_transposed_resident(wk, g_T, sparse, T, debug_stamps=None):
                                            None if rp is None else ctypes.byref(rp), stream_ptr)
 
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=4,
-                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, CSPN_F32), reports_done=True, guarded=bool(guard))
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, CSPN_F32), reports_done=True, guarded=bool(guard),
+                          out=ghist[int(T) - 1])
     _lib.check(ok, "cspnk_transposed_resident")
     return g32, ghist
 
@@ -1213,8 +1242,10 @@ def forward_resident(guidance, d0, sparse, T, blend, score=None, valid_w=0, step
             if scored:
                 evaluation.metric_sums(out, tgp, out=acc)
 
-    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo, out=out,
-                          inputs=(guidance, d0, sparse, tg), what="cspn3_forward_resident %dx%dx%d" % (B, H, W), guarded=bool(guard))
+    # (a training-form launch cannot be repaired after the fact: its entry keeps no inputs, and the plane a tile that gave up poisons weakly)
+    ok = _resident_launch(dev, B, H, W, int(T), launch, reports_done=bool(keep_history), redo=redo,
+                          out=hist[int(T) - 1] if keep_history else out, inputs=() if keep_history else (guidance, d0, sparse, tg),
+                          what="cspn3_forward_resident %dx%dx%d" % (B, H, W), guarded=bool(guard))
     _lib.check(ok, "cspn3_forward_resident")
     if keep_history:
         return hist[int(T) - 1], hist, w8, S_out
@@ -1369,7 +1400,8 @@ def pac_forward_resident_history(guided, x0, sparse, T):
 
     sdt = _dt(x0)
     ok = _resident_launch(dev, B, H, W, int(T), launch, ws_kind="k", state_bytes=x0.element_size(),
-                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), reports_done=True, guarded=bool(guard))
+                          ws_bytes_fn=lambda: L.cspnk_resident_workspace_bytes(B, H, W, sdt), reports_done=True, guarded=bool(guard),
+                          out=hist[int(T) - 1])
     _lib.check(ok, "cspnk_forward_resident_history")
     return hist[int(T) - 1], hist, wk
 
@@ -1483,7 +1515,7 @@ def _check_resident_at_end_of_backward(dev):
     kernels, the first of the backward pass, have long finished, so the wait is free in a real model.  The reference
     re-raises worker errors the same way, never swallowing them (network/libs/base/encoding.py:172-174, :193-194)."""
     st = _RES.get(dev.index)
-    if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing() or os.environ.get("CSPN_BWD_CHECK") == "off":
+    if st is None or not st["dirty"] or torch.cuda.is_current_stream_capturing() or _BWD_CHECK_OFF:
         return                     # (CSPN_BWD_CHECK=off: A/B switch for measurements; the next resident launch still raises)
     if not st.get("need_bwd_check"):
         return                     # every training-form launch since the last check carried its device-side guard (round 5): whatever
@@ -1502,6 +1534,10 @@ class _NoGradCtx(object):
     needs_input_grad = (False,) * 8
 
 
+# A/B switches read ONCE at import (they sat on the per-call path of CSPN3Function until round 6): CSPN_TRAIN_VOLUME=1 keeps the
+# 8-plane tap volume of the 3x3 training forward, CSPN_BWD_CHECK=off skips the end-of-backward host check (measurements only)
+_TRAIN_VOLUME = os.environ.get("CSPN_TRAIN_VOLUME", "0") == "1"
+_BWD_CHECK_OFF = os.environ.get("CSPN_BWD_CHECK") == "off"
 _TRAIN_FAST = {}       # call signature -> (cached guarded resident plan, blend): CSPN3Function's resident training form, checks done once
 
 
@@ -1532,7 +1568,7 @@ class CSPN3Function(torch.autograd.Function):
             d0 = blur_depth.view(B, H, W)
             sp = None if sparse_depth is None else sparse_depth.view(B, H, W)
             out, hist, w8, S = forward_resident(guidance, d0, sp, prop_time, hit[1], valid_w=valid_w, keep_history=True,
-                                                publish_weights=os.environ.get("CSPN_TRAIN_VOLUME", "0") == "1", guard=1, _plan=hit[0])
+                                                publish_weights=_TRAIN_VOLUME, guard=1, _plan=hit[0])
             ctx.save_for_backward(guidance, w8, S, d0, sp, hist)
             ctx.prop_time, ctx.plan, ctx.valid_w = prop_time, None, valid_w
             ctx.in_shape = tuple(blur_depth.shape)
@@ -1556,7 +1592,7 @@ class CSPN3Function(torch.autograd.Function):
             # (S only: the reverse sweep and the tail rebuild the taps from guidance + S — no 8-plane volume to write or read;
             #  CSPN_TRAIN_VOLUME=1 keeps it, for A/B runs)
             out, hist, w8, S = forward_resident(g, d0, sp, prop_time, blend, valid_w=valid_w, keep_history=True,
-                                                publish_weights=os.environ.get("CSPN_TRAIN_VOLUME", "0") == "1")
+                                                publish_weights=_TRAIN_VOLUME)
             if key is not None and prop_time <= _GUARD_MAX_T and blur_depth.dim() == 4 and (sparse_depth is None or sparse_depth.dim() == 4):
                 # remember: this signature is served by the resident training form (with the guard: no host check at the end of backward)
                 cp = _with_spin_limit(_resident_plan_cached(B, H, W, int(prop_time), int(blend), guidance.device)[1], guard=1)
@@ -1753,19 +1789,20 @@ class _ScoredFast(object):
 
     def issue(self, guidance, d0, sparse, target, acc):
         st = self.st
-        work = st["work"].get(self.wkey)
-        if work is not self.work:                      # the workspace cache was started over (more than 16 shapes): pick up the new one
-            self.work = work
-        if (_EVENT_LOG is not None or _RESIDENT_SPIN_LIMIT or work is None
+        if (_EVENT_LOG is not None or _RESIDENT_SPIN_LIMIT
                 or torch._C._cuda_getDevice() != self.idx or torch._C._cuda_isCurrentStreamCapturing()):
             return None
         raw = torch._C._cuda_getCurrentRawStream(self.idx)
-        if raw != st.get("last_raw") or st["seq"] > _RES_SEQ_MAX:
-            return None
         out = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
         B, H, W, T, blend = self.B, self.H, self.W, self.T, self.blend
         guarded = _RESIDENT_GUARD == "all" and self.plan_guarded is not None
         with st["lock"]:
+            # everything another thread's launch can change is read under the device's lock (read before it, a launch from
+            # another stream in between let this one skip wait_stream and overlap a resident launch — time-outs, not wrong output)
+            work = st["work"].get(self.wkey)
+            if work is None or raw != st.get("last_raw") or st["seq"] > _RES_SEQ_MAX:
+                return None                        # stream change / evicted workspace / sequence wrap: the general path
+            self.work = work                       # (the workspace cache may have been started over: more than 16 shapes)
             if st["host_err_np"][0] != 0:
                 _recover(self.dev, st)
             seq = st["seq"]

@@ -137,8 +137,15 @@ class Simple_Gudi_UpConv_Block_Last_Layer(_UpBlock):             # unet_cspn_nyu
         super(Simple_Gudi_UpConv_Block_Last_Layer, self).__init__(oheight, owidth)
         self.conv1 = _conv(in_channels, out_channels, 3)
 
-    def forward(self, x):
-        return self.conv1(self._up_pooling(x))
+    def forward(self, x, out_channels=None):
+        """out_channels < conv1.out_channels: only the first `out_channels` filters are run (the parameter keeps its shape — the
+        reference's state_dict — and autograd hands the filters that did not run a zero gradient, which is what they get from the
+        CSPN module anyway: it reads channels 0..7 of the 12, CSPN_new.py:29-36)."""
+        x = self._up_pooling(x)
+        if out_channels is None or out_channels >= self.conv1.out_channels:
+            return self.conv1(x)
+        c = self.conv1
+        return nn.functional.conv2d(x, c.weight[:out_channels], None, c.stride, c.padding, c.dilation, c.groups)
 
 
 class ResNet(nn.Module):
@@ -146,10 +153,15 @@ class ResNet(nn.Module):
 
     decoder_sizes: the five (oheight, owidth) pairs of the decoder stages; the default is the reference's hard-coded
     228 x 304 pyramid (:327-332).  prop_time / prop_kernel: the reference hard-codes (24, 3) (:357-358).
-    `return_cspn_io=True` makes forward also return (guidance, coarse, sparse) — the tensors handed to the CSPN module."""
+    `return_cspn_io=True` makes forward also return (guidance, coarse, sparse) — the tensors handed to the CSPN module.
+    affinity_channels (round 6, SURVEY.md §8 f1 "emit only 8 channels instead of 12"): how many of the affinity head's 12 filters
+    (:332) the forward runs.  The default 8 is all the CSPN module reads (CSPN_new.py:29-36): the head's last convolution, its
+    weight-gradient work and the [B,12,H,W] write shrink by a third (27 MB less per forward at B = 24), the refined depth and the
+    gradients of channels 0..7 are unchanged (the 4 dead filters received exact zeros before, and receive them now), the parameter
+    and the state_dict keep the reference's [12,64,3,3] shape.  12 reproduces the reference's tensor (guidance [B,12,H,W])."""
 
     def __init__(self, block, layers, up_proj_block=UpProj_Block, decoder_sizes=DECODER_SIZES_NYU, prop_time=24,
-                 prop_kernel=3, reference_state_dict=True, cspn_plan=None):
+                 prop_kernel=3, reference_state_dict=True, cspn_plan=None, affinity_channels=8):
         super(ResNet, self).__init__()
         self.inplanes = 64
         e = block.expansion
@@ -178,6 +190,9 @@ class ResNet(nn.Module):
         self.gud_up_proj_layer4 = Gudi_UpProj_Block_Cat(64 * e, 64, *s[3])
         self.gud_up_proj_layer5 = Simple_Gudi_UpConv_Block_Last_Layer(64, 1, *s[4])       # coarse depth head
         self.gud_up_proj_layer6 = Simple_Gudi_UpConv_Block_Last_Layer(64, 12, *s[4])      # affinity head (8 of 12 used)
+        if not 8 <= int(affinity_channels) <= 12:
+            raise ValueError("affinity_channels must be in [8, 12] (the CSPN module reads channels 0..7)")
+        self.affinity_channels = int(affinity_channels)
         self.return_cspn_io = False
 
     def _make_layer(self, block, planes, blocks, stride=1):
@@ -196,7 +211,7 @@ class ResNet(nn.Module):
         return [p for n in names if hasattr(self, n) for p in getattr(self, n).parameters()]
 
     def features(self, x):
-        """Everything below the CSPN module: (guidance [B,12,H,W], coarse [B,1,H,W], sparse [B,1,H,W])."""
+        """Everything below the CSPN module: (guidance [B,affinity_channels,H,W], coarse [B,1,H,W], sparse [B,1,H,W])."""
         sparse_depth = x.narrow(1, 3, 1).clone()                       # :362
         x = self.conv1_1(x)
         skip4 = x                                                      # pre-BN stem output, 64 ch at H/2 (:364)
@@ -209,7 +224,7 @@ class ResNet(nn.Module):
         x = self.gud_up_proj_layer2(x, skip2)
         x = self.gud_up_proj_layer3(x, skip3)
         x = self.gud_up_proj_layer4(x, skip4)
-        return self.gud_up_proj_layer6(x), self.gud_up_proj_layer5(x), sparse_depth
+        return self.gud_up_proj_layer6(x, self.affinity_channels), self.gud_up_proj_layer5(x), sparse_depth
 
     def forward(self, x):
         guidance, coarse, sparse_depth = self.features(x)

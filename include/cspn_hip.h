@@ -39,6 +39,8 @@
  * columns [W_valid, W) are then treated exactly like pixels outside the image — zero gate, zero depth, forced to
  * 0 after every step — which is the reference's own boundary condition, so in-image results are unchanged.
  * (Plain zero padding WITHOUT W_valid is not equivalent: pad pixels with an all-zero neighbourhood become 0/0.)
+ * Outputs: the padding columns of the last valid quad, [W_valid, round_up4(W_valid)), receive zeros (also from the guard's
+ * re-computation of a timed-out resident launch); columns beyond that quad are not written at all.
  * With W % 4 != 0 and no padding the library falls back to generic one-pixel-per-thread kernels.
  *
  * Tap-volume layout (the `w8` / `wk` / `wT` buffers; produced and consumed only by this library):

@@ -213,6 +213,39 @@ def test_journal_entries_demote_to_weak_references():
     assert e.resolve()[1] is None                     # an input is gone: the call cannot be re-run
 
 
+def test_journal_entries_accept_inference_tensors_and_training_entries_pin_nothing():
+    """ADVICE r5.  (1) Tensors made under torch.inference_mode() have no version counter (reading it raises): a journal entry
+    built from them — every unguarded launch builds one, the default scored forward among them — records "cannot verify" instead
+    of crashing after the kernel was enqueued, and the repair trusts such inputs.  (2) A training-form entry (redo None) keeps no
+    inputs and holds the plane a failed tile poisons weakly from the start."""
+    import gc
+    from cspn_monodepth_amd import functional as F
+    with torch.inference_mode():
+        g = torch.ones(2, 12, 4, 8)
+        d0 = torch.ones(2, 4, 8)
+        out = torch.zeros(2, 4, 8)
+        assert g.is_inference()
+        e = F._JournalEntry(lambda *a: None, out, (g, d0, None, None), "test")
+        assert e.versions[0] is F._NO_VERSION and e.versions[2] is None
+        assert e.untouched(e.inputs)
+        e.demote()
+        o2, ins = e.resolve()
+        assert o2.data_ptr() == out.data_ptr() and e.untouched(ins)
+    # mixed: an ordinary tensor next to an inference one is still checked
+    h = torch.ones(2, 4, 8)
+    e2 = F._JournalEntry(lambda *a: None, torch.zeros(1), (g, h), "test")
+    h.add_(1.0)
+    assert not e2.untouched(e2.inputs)
+    # training form: no inputs, weak output, nothing pinned
+    hist = torch.zeros(3, 2, 4, 8)
+    e3 = F._JournalEntry(None, hist[2], (g, h), "training")
+    assert e3.inputs == () and e3.weak and e3.nbytes == 0
+    assert e3.out.get().data_ptr() == hist[2].data_ptr()
+    del hist
+    gc.collect()
+    assert e3.out.get() is None
+
+
 def test_bench_cpu_binding_narrows_and_restores_the_affinity_mask():
     """bench.py --cpu-bind auto: a rank's host threads go to its share of the first allowed cores; the CPU baseline leg gets the
     whole mask back (full_affinity), and the reported host budget is the original one."""

@@ -44,6 +44,15 @@ def test_single_process_json_line():
     assert "frac" not in f and f["compulsory_bytes_per_forward"] == 11 * 4 * 24 * 228 * 304
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert len(c["value_range"]) == 2 and c["value_range"][0] <= c["value"] <= c["value_range"][1]      # min-max over the best leg's repetitions
+    assert c["range_over_legs"][0] <= c["range_over_legs"][1]
+    sv = d["sparse_variant"]                # the variant the reference's call site runs (sparse_depth always passed), same process
+    assert sv["value"] > 0 and sv["bytes_per_px_step"] == 48 and abs(sv["value"] - 24 / (sv["ms_per_step"] / 1e3)) < 1e-6 * sv["value"]
+    assert sv["roofline"]["algorithmic_bytes_per_launch"] == 48 * 24 * 228 * 304 and 0.4 < sv["roofline"]["frac"] < 1.0
+    assert sv["metrics_check"]["count"] > 0
+    so = d["stock_ops_same_gpu"]            # the reference's own GPU path (stock ATen ops; the op-mix port) on this GPU, untimed region
+    assert so["kind"] == "port" and so["batch"] == 24 and 0 < so["maps_per_s"] < d["value"]
+    assert so["aten_ops_per_forward"] > 24 * 10 and so["max_rel_diff_hip_vs_stock_ops"] < 1e-4
     assert d["cache_cold"]["footprint_MB"] > 256
     assert d["metrics_check"]["count"] > 0
 

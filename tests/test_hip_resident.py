@@ -346,7 +346,7 @@ def test_training_step_without_the_tap_volume_equals_the_one_with_it(B, H, W, T,
         cot = dev(c_oracle.hash_normal(231, 9, (B, 1, H, W)))
         res = []
         for keep in ("0", "1"):
-            monkeypatch.setenv("CSPN_TRAIN_VOLUME", keep)
+            monkeypatch.setattr(F, "_TRAIN_VOLUME", keep == "1")      # (the environment variable is read once, at import)
             gt, dt = dev(g).requires_grad_(True), dev(d).requires_grad_(True)
             out = pkg.CSPN_new.AffinityPropagate(T, 3)(gt, dt, dev(s) if sparse else None)
             out.backward(cot)

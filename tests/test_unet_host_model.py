@@ -69,7 +69,8 @@ def test_full_network_matches_reference_and_cspn_pair_matches_oracle(c_oracle):
         out, (g, c, s) = m(torch.from_numpy(np.concatenate([rgb, sp], 1)).cuda())
     sub = int(z["sub"])
     o, gn, cn = out.cpu().numpy(), g.cpu().numpy(), c.cpu().numpy()
-    for got, want in ((gn[:, :, ::sub, ::sub], z["guidance_sub"]), (cn[:, :, ::sub, ::sub], z["coarse_sub"]),
+    assert gn.shape[1] == 8 and g.is_contiguous()      # round 6: the head runs the 8 filters the module reads; golden channels 0..7 unchanged
+    for got, want in ((gn[:, :, ::sub, ::sub], z["guidance_sub"][:, :8]), (cn[:, :, ::sub, ::sub], z["coarse_sub"]),
                       (o[:, :, ::sub, ::sub], z["out_sub"])):
         scale = float(np.abs(want).max())
         assert float(np.abs(got - want).max()) <= 2e-3 * scale          # ~170 stacked fp32 convolutions, MIOpen vs oneDNN
@@ -78,6 +79,36 @@ def test_full_network_matches_reference_and_cspn_pair_matches_oracle(c_oracle):
     # the same form as the G8 hook golden — not per pixel against |want| -> 0)
     want = c_oracle.cspn3_forward(gn, cn, s.cpu().numpy(), 24)
     assert float(np.abs(o - want).max()) <= 1e-5 * float(np.abs(want).max()) and rmse(o, want) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_eight_filter_affinity_head_equals_the_twelve_filter_one_where_it_matters():
+    """SURVEY.md §8 f1 / VERDICT r5 next #4: the affinity head runs the 8 filters the CSPN module reads (default) instead of the
+    reference's 12 (unet_cspn_nyu.py:332).  Same parameters (state_dict shape [12,64,3,3] kept), same guidance on channels 0..7,
+    same refined depth, same gradients for everything that had a non-zero gradient before — and exact zeros for filters 8..11,
+    which is what the module's backward gave them anyway (CSPN_new.py:29-36 never reads those channels)."""
+    from cspn_monodepth_amd.network import unet_cspn_nyu as net
+    torch.manual_seed(7)
+    m12 = net.resnet50(reference_state_dict=False, affinity_channels=12).cuda().train()
+    m8 = net.resnet50(reference_state_dict=False).cuda().train()
+    m8.load_state_dict(m12.state_dict())
+    assert m8.affinity_channels == 8 and tuple(m8.gud_up_proj_layer6.conv1.weight.shape) == (12, 64, 3, 3)
+    m8.return_cspn_io = m12.return_cspn_io = True
+    B, H, W = 2, 228, 304
+    depth = torch.rand(B, 1, H, W, device="cuda") * 9.5 + 0.5
+    sparse = depth * (torch.rand(B, 1, H, W, device="cuda") < 500.0 / (H * W))
+    x = torch.cat([torch.rand(B, 3, H, W, device="cuda"), sparse], 1)
+    res = []
+    for m in (m12, m8):
+        out, (g, c, s) = m(x)
+        (depth - out).abs().mean().backward()
+        res.append((out.detach(), g.detach(), m.gud_up_proj_layer6.conv1.weight.grad.clone(), m.conv1_1.weight.grad.clone()))
+    (o12, g12, w12, st12), (o8, g8, w8, st8) = res
+    assert g12.shape[1] == 12 and g8.shape[1] == 8 and g8.is_contiguous()
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)      # noqa: E731
+    assert close(g8, g12[:, :8], 1e-5) and close(o8, o12, 2e-5)            # (MIOpen may pick another algorithm for 8 output channels)
+    assert float(w12[8:].abs().max()) == 0.0 and float(w8[8:].abs().max()) == 0.0      # dead filters: exact zeros, before and now
+    assert close(w8[:8], w12[:8], 2e-3) and close(st8, st12, 2e-3)
 
 
 @pytest.mark.gpu
