@@ -750,10 +750,11 @@ def _recover(dev, st):
                 if e.redo is None:
                     # an unguarded training-form launch: decided per entry, as the inference entries are (one CLEAN
                     # training entry in the journal turned a guarded — already repaired — time-out of another launch into a raise).
-                    # Its `out` is the plane a tile that gave up poisons (d_T / G_0); dropped by the caller = nobody can read it;
-                    # never recorded = cannot tell, so it counts as failed.
+                    # Its `out` is the plane a tile that gave up poisons (d_T / G_0), held weakly.  Alive and clean: this launch
+                    # finished.  Freed — the reverse sweep's history dies with `backward`, AFTER the tail has read it on the GPU — or
+                    # never recorded: cannot tell, so it counts as failed (gradients built on it may already be in .grad).
                     tout = e.out.get() if isinstance(e.out, _WeakT) else e.out
-                    if (e.out is None) or (tout is not None and _holds_poison(tout)):
+                    if tout is None or _holds_poison(tout):
                         training = True
                     continue
                 out, ins = e.resolve()
