@@ -108,6 +108,19 @@ __device__ __forceinline__ void st4(gptr p, float4 v) {
 #ifndef CSPN_RES_HIST_NT
 #define CSPN_RES_HIST_NT 1
 #endif
+// Round 6, measured and NOT the default (NEGATIVE_RESULTS #53-#55; profiles/r06_step_pipe_ab.txt): the step's LDS round trips.  A step is
+//   barrier -> ds_read of the two halo rows -> wait -> DPP of all rows -> exec-masked ds_read of the strip-end lanes' columns -> wait -> FMAs
+//   -> ds_write -> wait -> barrier:  two LDS read latencies in series behind every barrier.
+// -DCSPN_RES_STEP_PIPE=1 takes the own rows' neighbour columns (DPP: registers of the neighbouring lanes, no LDS) BEFORE the barrier, from the rows
+// just computed, in the shadow of the ds_write latency, and issues EVERY LDS read of the step right behind the barrier (the halo rows' strip-end
+// columns into temporaries, merged with one select after the halo rows' DPP): one read latency instead of two, bit-identical — and SLOWER on every
+// shape (config 2 +1.6 us, shards +1.0 / +1.2 us).  The two perf-only experiments below say why nothing of this kind can pay: without ANY
+// strip-end read the forward is no faster (+-0.3 us), and without ANY step barrier it gains 2.3 us at config 2, 0.4 us at NYU B = 3, 1.4 us at
+// KITTI B = 1 — the step is bound by VALU issue (one instruction per wavefront every ~5 cycles, 2.5 per SIMD with its two wavefronts:
+// tools/probes/vgpr_bank_probe.hip), not by its barrier or its LDS latency, so "two steps per barrier" (+20..100 % FMAs for half of that) loses.
+#ifndef CSPN_RES_STEP_PIPE
+#define CSPN_RES_STEP_PIPE 0
+#endif
 #ifndef CSPN_RES_PUBLISH_ALL
 #define CSPN_RES_PUBLISH_ALL 1      // 0: only the quads a neighbour will read are published — 6 MB less traffic per forward at config 2 but
                                     // NOT faster (same-box A/B, profiles/r05_publish_ab.txt: 48.0 vs 47.8 us, sparse 53.9 vs 53.1): kept for A/B runs
@@ -524,6 +537,7 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
     const int n_phase = (a.T + a.S - 1) / a.S;
     const int tile_global = b * tiles_per_img + trem;
     float own[NQ][4];
+    float nbl[NQ], nbr[NQ];                    // -DCSPN_RES_STEP_PIPE=1: columns xq-1 / xq+4 of the own rows as the neighbouring lanes hold them (DPP)
 
     for (int p = 0; p < n_phase; ++p) {
         const int steps = (a.T - p * a.S) < a.S ? (a.T - p * a.S) : a.S;
@@ -597,6 +611,10 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
             const v4f mid = *(lds_cv4f_ptr)(cur + drow * ls + cb);
             own[i][0] = mid.x; own[i][1] = mid.y; own[i][2] = mid.z; own[i][3] = mid.w;
         }
+        if (CSPN_RES_STEP_PIPE) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { nbl[i] = dpp_from_prev_lane(own[i][3]); nbr[i] = dpp_from_next_lane(own[i][0]); }
+        }
         if (BLEND && !TRANS && p == 0) {           // private slots: m -> m * d0 (own = d0 here)
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -627,10 +645,49 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
                     drow = drow < dr ? drow : dr - 1;
                     return rd + drow * ls + cb;
                 };
+                if (CSPN_RES_STEP_PIPE) {
+                    // every LDS read of the step is issued right behind the barrier: the two halo rows' quads, then — exec-masked, strip-end /
+                    // wave-edge lanes only — the own rows' neighbour columns (straight into the window, over the DPP values taken before the
+                    // barrier) and the halo rows' (into temporaries: the DPP of a halo row has to wait for its quad, the read need not)
+                    v4f hq[2 * R];
+                    float tl[2 * R], tr[2 * R];
+#pragma unroll
+                    for (int h = 0; h < 2 * R; ++h) {
+                        hq[h] = *(lds_cv4f_ptr)(row_ptr(h < R ? h : NQ + h));
+                        tl[h] = 0.f; tr[h] = 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) win[i + R][R + c] = own[i][c];
+                        win[i + R][0] = nbl[i]; win[i + R][5] = nbr[i];
+                    }
+                    if (fix_left) {
+#pragma unroll
+                        for (int i = 0; i < NQ; ++i) win[i + R][0] = row_ptr(i + R)[-1];
+#pragma unroll
+                        for (int h = 0; h < 2 * R; ++h) tl[h] = row_ptr(h < R ? h : NQ + h)[-1];
+                    }
+                    if (fix_right) {
+#pragma unroll
+                        for (int i = 0; i < NQ; ++i) win[i + R][5] = row_ptr(i + R)[4];
+#pragma unroll
+                        for (int h = 0; h < 2 * R; ++h) tr[h] = row_ptr(h < R ? h : NQ + h)[4];
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2 * R; ++h) {
+                        const int rr = h < R ? h : NQ + h;
+                        win[rr][1] = hq[h].x; win[rr][2] = hq[h].y; win[rr][3] = hq[h].z; win[rr][4] = hq[h].w;
+                        const float dl = dpp_from_prev_lane(hq[h].w), dr2 = dpp_from_next_lane(hq[h].x);
+                        win[rr][0] = fix_left ? tl[h] : dl;
+                        win[rr][5] = fix_right ? tr[h] : dr2;
+                    }
+                } else {
 #pragma unroll
                 for (int rr = 0; rr < NQ + 2 * R; ++rr) {
                     float m4[4];
-                    if (rr >= R && rr < R + NQ) {
+                    const bool own_row = rr >= R && rr < R + NQ;
+                    if (own_row) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) m4[c] = own[rr - R][c];
                     } else {
@@ -644,13 +701,22 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
                 }
                 // strip-end / wave-edge lanes patch their halo column from LDS: exec-masked ds_read straight into the window
                 // registers (a merged block with selects costs 28 v_mov per step and measured 7 % slower)
+#ifdef CSPN_RES_EXPERIMENT_NOFIX      // perf experiment ONLY (wrong results): what do the masked 4-byte reads cost?
+                if (false) {
+#else
                 if (fix_left) {
+#endif
 #pragma unroll
                     for (int rr = 0; rr < NQ + 2 * R; ++rr) win[rr][0] = row_ptr(rr)[-1];
                 }
+#ifdef CSPN_RES_EXPERIMENT_NOFIX
+                if (false) {
+#else
                 if (fix_right) {
+#endif
 #pragma unroll
                     for (int rr = 0; rr < NQ + 2 * R; ++rr) win[rr][5] = row_ptr(rr)[4];
+                }
                 }
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
@@ -700,7 +766,17 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
                 }
             }
             if (HIST) hist_step += plane;
+            if (CSPN_RES_STEP_PIPE && !FINAL && decltype(on_c)::value) {
+                // the next step's neighbour columns of the own rows, in the shadow of the ds_write latency (pinned in front of the barrier)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    nbl[i] = dpp_from_prev_lane(own[i][3]); nbr[i] = dpp_from_next_lane(own[i][0]);
+                    asm volatile("" : "+v"(nbl[i]), "+v"(nbr[i]));
+                }
+            }
+#ifndef CSPN_RES_EXPERIMENT_NOBARRIER  // perf experiment ONLY (wrong results): what do the step barriers cost?
             if (!FINAL) __syncthreads();
+#endif
         };
         stamp();                               // depth staged
         const int plain_steps = last_phase ? steps - 1 : steps;
