@@ -640,6 +640,10 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
                 // kept (spilled) across the hot loop
                 int r0x = r0L, yqx = yq0L;
                 if (FINAL) asm volatile("" : "+v"(r0x), "+v"(yqx));
+                // ... and ONE pixel offset for its stores: formed per row from the strip coordinates, a spilled coordinate was reloaded from
+                // scratch — with a wait for the reload — in front of every row's store (5 x ~0.7 us in the blended scored instance: round 6)
+                unsigned o0x = 0u;
+                if (FINAL && !HIST) { o0x = (unsigned)(yqx * W + xqL); asm volatile("" : "+v"(o0x)); }
                 auto row_ptr = [&](int rr) -> const float* {
                     int drow = r0x + rr;
                     drow = drow < dr ? drow : dr - 1;
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
                         if (HIST) {
                             if ((interior >> i) & 1u) st4_hist(at32(hist_step, (unsigned)((yq0L + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
                         } else if (FINAL && ((interior >> i) & 1u)) {
-                            st4(at32(dout, (unsigned)((yqx + i) * W + xqL)), make_float4(u[0], u[1], u[2], u[3]));
+                            st4(at32(dout, o0x + (unsigned)(i * W)), make_float4(u[0], u[1], u[2], u[3]));
                         }
                     }
                 }
@@ -839,9 +843,11 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
             if (tid < 9 && tid != 4) {
                 const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
                 if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
-                    const unsigned* f = a.flags + b * tiles_per_img + ny * a.tiles_x + nx;
+                    // (SGPR base + a 32-bit VGPR offset: as a 64-bit per-thread pointer the flag address was spilled in the blended instances and
+                    //  re-loaded from scratch — with a wait — in front of EVERY poll)
+                    const gptr f = (gptr) reinterpret_cast<unsigned long long>(uniform_ptr(a.flags)) + ((unsigned)(b * tiles_per_img + ny * a.tiles_x + nx) << 2);
                     unsigned spins = 0;
-                    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                    while ((int)(__hip_atomic_load(reinterpret_cast<const GLB unsigned*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
                         ++spins;
                         if ((spins & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
                             wg_bad = 1;
@@ -890,10 +896,12 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
             // round trip costs less than carrying NQ quads through the final step did
             float4 scored_t[NQ];
             const float* tgt_b = uniform_ptr(a.target + (size_t)b * HW);
+            unsigned o0s = (unsigned)(yq0L * W + xqL);       // one offset for all rows (see the final step's stores)
+            asm volatile("" : "+v"(o0s));
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const bool in = (interior >> i) & 1u;
-                scored_t[i] = ld4(at32(tgt_b, in ? (unsigned)((yq0L + i) * W + xqL) : 0u));
+                scored_t[i] = ld4(at32(tgt_b, in ? o0s + (unsigned)(i * W) : 0u));
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {

@@ -89,6 +89,9 @@ __device__ __forceinline__ void softmax_to_pairs(const unsigned (&w)[24], float 
 }
 
 constexpr int D2_R = 2, D2_NT = 24;
+#ifndef CSPN_D2_DPP_HALO
+#define CSPN_D2_DPP_HALO 0          // round 6, measured and NOT the default (1 for A/B): see the step
+#endif
 
 // MODE 0: inference; 1: inference + fused depth metrics; 2: the training forward — every step's state goes to its fp16 history
 // plane and the softmax taps are published once as the fp16 tap volume (pairs (2i, 2i+1) interleaved per quad: cspn_common.hpp
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
     const bool in_img = active && xo < W && yo < H;        // W % 8 == 0: an oct is inside the image or outside as a whole
     const bool interior = in_img && yo >= y0 && yo < y0 + a.th && xo >= x0 && xo < x0 + a.tw;
     const unsigned off_own = in_img ? (unsigned)(yo * W + xo) : 0u;
+#if CSPN_D2_DPP_HALO
+    const bool fix_left = (sx == 0) || ((tid & 63) == 0), fix_right = (sx == wo - 1) || ((tid & 63) == 63);
+    const int colL = fix_left ? 4 * (sx + 1) - 1 : 0, colR = fix_right ? 4 * (sx + 1) + 4 : 0;      // dword 0 of a row: padding, one address per row
+#endif
 
     // LDS: two depth buffers of dr rows x ls dwords; a row is [3 pad][ring pair][wo octs x 4 dwords][ring pair][pad]: oct k at
     // dword 4 (k + 1) (16-byte aligned), the pixel pair left of the row at dword 3, the pair right of it at dword 4 (wo + 1)
@@ -396,8 +403,23 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
                     const unsigned* rowp = rd + drow * ls + 4 * (sx + 1);
                     unsigned D[6], U[5];
                     const v4uu d4 = *(lds_cv4u_ptr)(rowp);
+#if CSPN_D2_DPP_HALO
+                    // the pixel pairs left / right of the oct are the neighbouring lanes' d4.w / d4.x (DPP wave shift: VALU, no LDS); only the
+                    // strip-end / wave-edge lanes need LDS, and every other lane reads one dword per region row there (a broadcast) — the two
+                    // 4-byte reads per lane at a 16-byte stride are 4-way bank conflicts: 54 % of this kernel's LDS cycles (profiles/r05_sq_pac5.json).
+                    // MEASURED (NEGATIVE_RESULTS #56): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.539 -> 0.059, LDS cycles halved — and the forward
+                    // 69.8 -> 74.4 us: the step is VALU-bound (v_dot2 / v_fma_mix issue at ~4.6 cycles), the conflicts hide under it, and the 10
+                    // DPP moves + 10 selects per step are 13 % more VALU work (profiles/r06_d2_dpp_halo_ab.txt, r06_sq_pac5_dpp_halo.json)
+                    const unsigned* rowb = rd + drow * ls;
+                    const unsigned lfix = *(lds_cu_ptr)(rowb + colL), rfix = *(lds_cu_ptr)(rowb + colR);
+                    const unsigned ldpp = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d4.w, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                    const unsigned rdpp = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d4.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+                    D[0] = fix_left ? lfix : ldpp;
+                    D[5] = fix_right ? rfix : rdpp;
+#else
                     D[0] = *(lds_cu_ptr)(rowp - 1);
                     D[5] = *(lds_cu_ptr)(rowp + 4);
+#endif
                     D[1] = d4.x; D[2] = d4.y; D[3] = d4.z; D[4] = d4.w;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) U[k] = __builtin_amdgcn_alignbit(D[k + 1], D[k], 16);      // pixels (2k - 1, 2k)
