@@ -22,8 +22,9 @@ int resident_pac3_f32(const void* guided, const void* x0, const void* sparse, vo
                       int nslots, const cspn_resident_plan* plan, void* stream);
 // cspnk_d2.hip: the K = 5 fp16 form with the state packed as fp16 pairs in LDS and v_dot2_f32_f16 steps (launched by cspnk_forward_resident)
 int kres_d2_row_stride(int wo);
-size_t kres_d2_lds_bytes(int dr, int ls, int threads);
-int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, void* stream);   // mode 0 plain, 1 scored, 2 history
+size_t kres_d2_lds_bytes(int dr, int ls, int threads, int npf);
+int kres_d2_prefetch_channels(int dr, int ls, int threads, int rounds);      // guidance channels staged through LDS (0 or 8)
+int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, int npf, void* stream);   // mode 0 plain, 1 scored, 2 history
 // pac_conv2d_s2.hip: the pixel-adaptive convolution and its gradients for stride 2 x 2, dilation 1, K in {3, 5}, padding K / 2,
 // W % 8 == 0 (launched by the cspn_pac_conv2d* entry points of pac_conv2d.hip when every base pointer is 16-byte aligned)
 struct PacS2Args {

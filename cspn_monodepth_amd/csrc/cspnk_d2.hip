@@ -89,6 +89,10 @@ __device__ __forceinline__ void softmax_to_pairs(const unsigned (&w)[24], float 
 }
 
 constexpr int D2_R = 2, D2_NT = 24;
+constexpr int D2_NPF = 8;           // guidance channels of a round that are staged through LDS (a third of the 24)
+#ifndef CSPN_D2_PREFETCH
+#define CSPN_D2_PREFETCH 0          // round 6, BUILT, measured and NOT the default (NEGATIVE_RESULTS #57): see cspnk_d2's NPF
+#endif
 #ifndef CSPN_D2_DPP_HALO
 #define CSPN_D2_DPP_HALO 0          // round 6, measured and NOT the default (1 for A/B): see the step
 #endif
@@ -96,7 +100,16 @@ constexpr int D2_R = 2, D2_NT = 24;
 // MODE 0: inference; 1: inference + fused depth metrics; 2: the training forward — every step's state goes to its fp16 history
 // plane and the softmax taps are published once as the fp16 tap volume (pairs (2i, 2i+1) interleaved per quad: cspn_common.hpp
 // Taps<__half>) that cspn_transpose_kernel / cspn_grad_tail<5, __half, __half> stream in the backward.
-template <int BLEND, int MODE, int CLEAN, int NTH>
+// NPF (round 6; 0 or D2_NPF): the first NPF guidance channels of a round reach the registers THROUGH LDS (global_load_lds_dwordx4: no
+// destination registers) — and those of round r + 1 are requested as soon as round r's taps are derived, so that they stream while round
+// r's steps run (VALU-bound, the memory system idle) instead of in front of round r + 1's softmax.  Round 4 priced this (NEGATIVE_RESULTS
+// #35: "40 % of the region fits the free LDS ... a second staging protocol"); round 4's register form of the idea spilled (#38).
+// BUILT in round 6 (-DCSPN_D2_PREFETCH=1: a third of the guidance, 96 KB per workgroup; parity suite green, same bits) and SLOWER: 69.9 ->
+// 72.6 us per scored forward (profiles/r06_d2_prefetch_ab.txt).  The in-kernel stamps of the second round say why (r06_d2_prefetch_stamps.txt):
+// parked + derive + the barrier behind them 11.1 us without, 11.6 us with the prefetch — what a round spends in front of its steps is NOT
+// the guidance stream but the softmax itself, 192 v_exp_f32 per thread at a quarter of the VALU rate with three wavefronts per SIMD taking
+// turns (the loads hide under the other wavefronts' exponentials); the staging through LDS only adds instructions and 5 spilled registers.
+template <int BLEND, int MODE, int CLEAN, int NTH, int NPF>
 __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
     constexpr int R = D2_R, NT = D2_NT;
     constexpr bool SCORE = MODE == 1, HIST = MODE == 2;
@@ -168,6 +181,17 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
     const int yd0 = ry0 - R;
     const int step_r = NTH / wo, step_q = NTH - step_r * wo;
     const int n_phase = (a.T + a.S - 1) / a.S;
+    // the prefetch area: behind the two depth buffers and the scoring's partial sums, [NPF channels][NTH lanes] x 16 bytes — lane l of
+    // wavefront w finds channel c of its own oct at slot c * NTH + 64 w + l (the DMA writes M0 + 16 x lane: a wavefront reads what it wrote)
+    unsigned* const pf_lds = ldsu + ((2 * pp + (NTH / 64) * 10 + 16 + 3) & ~3);
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto prefetch = [&](int bimg, unsigned off) __attribute__((always_inline)) {
+        const __half* __restrict__ gbn = kuniform_ptr(static_cast<const __half*>(a.g) + (size_t)bimg * NT * HW);
+#pragma unroll
+        for (int c = 0; c < NPF; ++c)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const GLB void*>(atb(gbn, ((unsigned)c * HW + off) * 2u)),
+                                             (__attribute__((address_space(3))) void*)(pf_lds + (c * NTH + wave_u * 64) * 4), 16, 0, 0);
+    };
 
     for (int round = 0; round < a.rounds; ++round) {
         const int b = a.b0 + round * a.nb + bl;
@@ -215,8 +239,9 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
         // 64-bit pairs, spilled, and every scratch reload between the loads waits for the whole in-order stream)
         unsigned off_r = off_own;
         asm volatile("" : "+v"(off_r));
+        if (NPF > 0 && round == 0) prefetch(b, off_r);        // (later rounds: requested during the previous round's steps)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) graw[c] = ld16(atb(gb, ((unsigned)c * HW + off_r) * 2u));
+        for (int c = NPF; c < NT; ++c) graw[c] = ld16(atb(gb, ((unsigned)c * HW + off_r) * 2u));
         // sparse blend operands of the owned oct, behind the guidance
         Oct spo, x0o;
         if (BLEND) { spo = IO::ld_oct(spb, off_r); x0o = IO::ld_oct(x0b, off_r); }
@@ -257,6 +282,14 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
         stamp();                                              // depth region parked
 
         // ---- 2. softmax of the 8 owned pixels -> tap-pair registers -----------------------------------------------------
+        if (NPF > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of this wavefront's slots has landed (the softmax needs every channel anyway)
+#pragma unroll
+            for (int c = 0; c < NPF; ++c) {
+                const v4uu v = *(lds_cv4u_ptr)(pf_lds + (c * NTH + tid) * 4);
+                graw[c] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
         unsigned wq[8][12];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -308,6 +341,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
             }
         }
         stamp();                                              // weights derived
+        if (NPF > 0 && round + 1 < a.rounds) {
+            // the next round's first NPF channels stream into LDS while this round's steps run (the slots were read above; a workgroup's
+            // next image is b + nb, same tile, same offsets).  The phase boundaries' s_waitcnt vmcnt(0) also wait for them.
+            const int bn = b + a.nb;
+            if (bn < a.B) prefetch(bn, off_r);
+        }
 
         // ---- 3. phases of S steps; between phases the tile borders travel through the exchange planes --------------------
         __half* __restrict__ outb = HIST ? nullptr : kuniform_ptr(static_cast<__half*>(a.out) + (size_t)b * HW);
@@ -541,9 +580,9 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_d2(const KResArgs a) {
     count_out();
 }
 
-template <int BLEND, int MODE, int CLEAN, int NTH>
+template <int BLEND, int MODE, int CLEAN, int NTH, int NPF>
 int d2_launch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st) {
-    constexpr auto kern = cspnk_d2<BLEND, MODE, CLEAN, NTH>;
+    constexpr auto kern = cspnk_d2<BLEND, MODE, CLEAN, NTH, NPF>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
@@ -555,10 +594,10 @@ int d2_launch_inst(const KResArgs& a, int grid, size_t lds_bytes, hipStream_t st
     HIP_OK(hipGetLastError());
     return 1;
 }
-template <int NTH>
+template <int NTH, int NPF>
 int d2_launch_nth(const KResArgs& a, int grid, size_t lds, int blend, int mode, int clean, hipStream_t st) {
 #define D2_CASE(BL, MD, CL) \
-    if (blend == BL && mode == MD && clean == CL) return d2_launch_inst<BL, MD, CL, NTH>(a, grid, lds, st)
+    if (blend == BL && mode == MD && clean == CL) return d2_launch_inst<BL, MD, CL, NTH, NPF>(a, grid, lds, st)
     D2_CASE(0, 0, 0); D2_CASE(0, 0, 1); D2_CASE(0, 1, 0); D2_CASE(0, 1, 1); D2_CASE(0, 2, 0); D2_CASE(0, 2, 1);
     D2_CASE(1, 0, 0); D2_CASE(1, 0, 1); D2_CASE(1, 1, 0); D2_CASE(1, 1, 1); D2_CASE(1, 2, 0); D2_CASE(1, 2, 1);
 #undef D2_CASE
@@ -581,15 +620,28 @@ int kres_d2_row_stride(int wo) {
     return best;
 }
 
-size_t kres_d2_lds_bytes(int dr, int ls, int threads) {
-    return ((size_t)2 * dr * ls + (size_t)(threads / 64) * 10 + 16) * sizeof(unsigned);
+size_t kres_d2_lds_bytes(int dr, int ls, int threads, int npf) {
+    const size_t base = (((size_t)2 * dr * ls + (size_t)(threads / 64) * 10 + 16 + 3) & ~(size_t)3) * sizeof(unsigned);
+    return base + (size_t)npf * threads * 16;
 }
 
-int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, void* stream) {
+// Guidance channels that travel through LDS (cspnk_d2's NPF): D2_NPF when the launch has more than one round — only then is there a next
+// round to request early — and the prefetch area fits the 160 KB next to the depth buffers; else 0 (-DCSPN_D2_PREFETCH=0: never, for A/B).
+int kres_d2_prefetch_channels(int dr, int ls, int threads, int rounds) {
+    if (!CSPN_D2_PREFETCH || rounds < 2) return 0;
+    return kres_d2_lds_bytes(dr, ls, threads, D2_NPF) <= (size_t)160 * 1024 ? D2_NPF : 0;
+}
+
+int kres_d2_launch(const void* kres_args, int threads, int grid, size_t lds_bytes, int blend, int mode, int clean, int npf, void* stream) {
     const KResArgs& a = *static_cast<const KResArgs*>(kres_args);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (threads == 768) return d2_launch_nth<768>(a, grid, lds_bytes, blend, mode, clean, st);
-    if (threads == 512) return d2_launch_nth<512>(a, grid, lds_bytes, blend, mode, clean, st);
+    if (npf != 0 && npf != D2_NPF) return fail("cspnk_forward_resident (dot2 form): %d prefetched channels (0 or %d)", npf, D2_NPF);
+#if CSPN_D2_PREFETCH       // (the prefetching instances are only compiled into A/B builds)
+    if (npf && threads == 768) return d2_launch_nth<768, D2_NPF>(a, grid, lds_bytes, blend, mode, clean, st);
+    if (npf && threads == 512) return d2_launch_nth<512, D2_NPF>(a, grid, lds_bytes, blend, mode, clean, st);
+#endif
+    if (threads == 768) return d2_launch_nth<768, 0>(a, grid, lds_bytes, blend, mode, clean, st);
+    if (threads == 512) return d2_launch_nth<512, 0>(a, grid, lds_bytes, blend, mode, clean, st);
     return fail("cspnk_forward_resident (dot2 form): %d threads (512 or 768)", threads);
 }
 

@@ -895,13 +895,14 @@ int cspnk_forward_resident(const void* guided, int g_dtype, int K, const void* x
         return fail("cspnk_forward_resident: the dot-product step form exists for K = 5 with fp16 guidance, fp16 planes and one oct per thread");
     if (d2_able && rp.step_form != CSPN_STEP_FMA) {
         a.ls = cspn_detail::kres_d2_row_stride(g.wo);
-        const size_t ldsb = cspn_detail::kres_d2_lds_bytes(g.dr, a.ls, g.threads);
-        if (ldsb > 160 * 1024) return fail("cspnk_forward_resident: the dot-product form needs %zu bytes of LDS", ldsb);
         a.b0 = 0;
         a.nb = g.imgs_per_launch < B ? g.imgs_per_launch : B;
         a.rounds = ceil_div(B, a.nb);
         a.last_chunk = 1;
-        if (!cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, score, clean ? 1 : 0, stream)) return 0;
+        const int npf = cspn_detail::kres_d2_prefetch_channels(g.dr, a.ls, g.threads, a.rounds);
+        const size_t ldsb = cspn_detail::kres_d2_lds_bytes(g.dr, a.ls, g.threads, npf);
+        if (ldsb > 160 * 1024) return fail("cspnk_forward_resident: the dot-product form needs %zu bytes of LDS", ldsb);
+        if (!cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, score, clean ? 1 : 0, npf, stream)) return 0;
         // (the dot-product form rounds the state to half after every step)
         if (rp.guard) return cspn_detail::kres_repair_launch(guided, g_dtype, K, x0, sparse, out, state_dtype, a.status, seq, B, H, W, T, 1, blend ? 1 : 0, ncu, stream);
         return 1;
@@ -1044,13 +1045,14 @@ int cspnk_forward_resident_history(const void* guided, int g_dtype, int K, const
         a.ls = cspn_detail::kres_d2_row_stride(g.wo);
         a.spin_limit = rp.spin_limit ? rp.spin_limit : (4u << 20);
         a.dbg = rp.debug_stamps;
-        const size_t ldsb = cspn_detail::kres_d2_lds_bytes(g.dr, a.ls, g.threads);
-        if (ldsb > 160 * 1024) return fail("cspnk_forward_resident_history: %zu bytes of LDS", ldsb);
         a.b0 = 0;
         a.nb = g.imgs_per_launch < B ? g.imgs_per_launch : B;
         a.rounds = ceil_div(B, a.nb);
         a.last_chunk = 1;
-        if (!cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, 2, kregions_inside_image(g, H, W, T) ? 1 : 0, stream)) return 0;
+        const int npf = cspn_detail::kres_d2_prefetch_channels(g.dr, a.ls, g.threads, a.rounds);
+        const size_t ldsb = cspn_detail::kres_d2_lds_bytes(g.dr, a.ls, g.threads, npf);
+        if (ldsb > 160 * 1024) return fail("cspnk_forward_resident_history: %zu bytes of LDS", ldsb);
+        if (!cspn_detail::kres_d2_launch(&a, g.threads, a.nb * g.tiles_x * g.tiles_y, ldsb, blend, 2, kregions_inside_image(g, H, W, T) ? 1 : 0, npf, stream)) return 0;
         // the guard: a forward that gave up gets its T planes and its tap volume re-computed on the stream (cspn_repair.hip)
         if (rp.guard) return cspn_detail::kres_history_repair_launch(guided, x0, blend ? sparse : nullptr, history, wk_out, a.status, seq, B, H, W, T, blend ? 1 : 0, ncu, stream);
         return 1;
