@@ -1102,9 +1102,11 @@ def main():
             "dtype": wl["dtype"],
             "dtype_note": ("fp32 arithmetic and storage; parity bar 1e-5 relative / RMSE 1e-4 against the reference (north_star)"
                            if wl["dtype"] == "f32" else
-                           "fp16 storage (guidance, taps, depth planes), fp32 accumulation inside a step; parity bar of this configuration "
-                           "(the builder's, north_star states 1e-5 for fp32 only): 8e-3 x max / 3e-3 x max RMSE against the fp32 oracle on "
-                           "the fp16-rounded inputs (tests/test_hip_kres.py, tests/test_hip_production.py)"),
+                           "fp16 storage (guidance, taps, depth planes), fp32 accumulation inside a step; north_star states 1e-5 for fp32 "
+                           "only, so this configuration's bar is anchored on the REFERENCE's own half-precision run (golden G15, round 6: "
+                           "CSPN_ours under the default dtype float16 is 8.1e-4 x max / 2.4e-4 x max RMSE away from the fp32 result on "
+                           "fp16-rounded inputs; this path must be no further: measured 7.8e-4 / 2.3e-4, tests/test_hip_kres.py); the "
+                           "full-batch test keeps the older 8e-3 / 3e-3 guard rail (tests/test_hip_production.py)"),
             "data": "synthetic (guidance~N(0,1), coarse~U(0,10)m%s; inputs resident in HBM)" % (
                 ", 500-sample sparse depth" if args.sparse else ""),
             "config": {"workload": wl["name"], "batch_per_gpu": B_local, "H": wl["H"], "W": wl["W"], "K": K,

@@ -76,6 +76,27 @@ def test_pac_fp16_reference_quirk():
     assert kern16.shape[1] == 25
 
 
+@pytest.mark.parametrize("tag", ["nosp", "sp"])
+def test_g15_reference_half_precision_runs_keep_their_recorded_distance(tag, c_oracle):
+    """Golden G15 (round 6): the reference's CSPN_ours module on one full frame of fp16-rounded inputs, with fp16 taps + fp32 state and
+    in half precision end to end.  The C oracle (fp32) on the same inputs reproduces the distances recorded when the fixture was made —
+    the anchor the GPU test holds this package's fp16 paths to (tests/test_hip_kres.py)."""
+    z = load_golden("g15_k5_t12_fp16_frame_%s" % tag)
+    _, H, W = (int(v) for v in z["shape"])
+    T, K, seed = int(z["T"]), int(z["K"]), int(z["seed"])
+    gd = c_oracle.hash_normal(seed, 1, (1, K * K - 1, H, W)).astype(np.float16).astype(np.float32)
+    x = c_oracle.hash_uniform(seed, 2, (1, 1, H, W), 0.0, 10.0).astype(np.float16).astype(np.float32)
+    sp = c_oracle.hash_sparse(seed, 3, x, float(z["sparse_rate"])).astype(np.float16).astype(np.float32) if tag == "sp" else None
+    want = c_oracle.pac_forward(x, gd, sp, T)
+    scale = float(np.abs(want).max())
+    assert z["out_half"].dtype == np.float16 and z["out_taps16"].dtype == np.float32
+    for key, ek in (("out_taps16", "ref_err_taps16"), ("out_half", "ref_err_half")):
+        r = z[key].astype(np.float32)
+        assert abs(float(np.abs(r - want).max()) / scale - float(z[ek][0])) <= 1e-6
+        assert abs(rmse(r, want) / scale - float(z[ek][1])) <= 1e-6
+    assert float(z["ref_err_half"][0]) < 1e-3 and float(z["ref_err_taps16"][0]) < float(z["ref_err_half"][0])
+
+
 def test_metrics_golden():
     z = load_golden("g7_metrics")
     got, n = orc.evaluate_metrics(z["pred"], z["target"])
