@@ -396,7 +396,7 @@ def run_train(args, wl, world, rank, local_rank, device):
         from cspn_monodepth_amd.network import conv_tuning
         conv_db = conv_tuning.use_tuned_conv_db(rank=local_rank)
     torch.manual_seed(0)
-    model = unet_cspn_nyu.resnet50(reference_state_dict=False, cspn_plan=parse_plan(args.plan)).to(device)
+    model = unet_cspn_nyu.resnet50(reference_state_dict=False, cspn_plan=parse_plan(args.plan), affinity_channels=args.affinity_channels).to(device)
     if args.memory_format == "channels_last":      # stock-op layout choice only: the HIP ops take their planes contiguous
         model = model.to(memory_format=torch.channels_last)
     if world > 1:
@@ -504,6 +504,26 @@ def run_train(args, wl, world, rank, local_rank, device):
     elapsed = float(elapsed.item())
     fwd_us = sorted(a.elapsed_time(b) * 1e3 for a, b in zip(ev["f0"], ev["f1"]))
     bwd_us = sorted(a.elapsed_time(b) * 1e3 for a, b in zip(ev["b0"], ev["b1"]))
+    infer = None
+    if args.infer_batch > 0 and world == 1:
+        # the eval pipeline's model(input) (libs/trainers/single_gpu_trainer.py:129): UNet + CSPN, eval mode, no autograd
+        Bi = args.infer_batch
+        xi = torch.cat([torch.rand(Bi, 3, H, W, device=device, generator=gen),
+                        (torch.rand(Bi, 1, H, W, device=device, generator=gen) * 9.5 + 0.5) *
+                        (torch.rand(Bi, 1, H, W, device=device, generator=gen) < 500.0 / (H * W))], 1)
+        model.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                model(xi)
+            torch.cuda.synchronize()
+            ni = max(5, args.steps // 2)
+            ti = time.perf_counter()
+            for _ in range(ni):
+                model(xi)
+            torch.cuda.synchronize()
+            infer = {"batch": Bi, "ms_per_step": (time.perf_counter() - ti) / ni * 1e3, "steps": ni}
+            infer["maps_per_s"] = Bi / (infer["ms_per_step"] / 1e3)
+        model.train()
     med = lambda v: v[len(v) // 2] if v else None                           # noqa: E731
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -526,6 +546,9 @@ def run_train(args, wl, world, rank, local_rank, device):
                                        "+ history) and backward (reverse sweep + fused tail); the rest of the step is stock "
                                        "MIOpen/rocBLAS convolutions, batch-norm, the un-pooling kernel, SGD"},
                "loss_first_last": [lv[0], lv[-1]], "optimiser_steps_run": len(lv)}
+        res["config"]["affinity_channels"] = args.affinity_channels
+        if infer is not None:
+            res["inference_step"] = infer
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -564,6 +587,10 @@ def main():
                     help="--workload train: torch.backends.cudnn.benchmark (MIOpen find mode) as the reference's main.py:37; "
                          "slow first steps (minutes)")
     ap.add_argument("--no-metrics", action="store_true", help="leave the depth-metrics reduction out of the step")
+    ap.add_argument("--affinity-channels", type=int, default=8,
+                    help="--workload train: filters of the affinity head the forward runs (8 = what the CSPN module reads, round 6; 12 = the reference's tensor)")
+    ap.add_argument("--infer-batch", type=int, default=0,
+                    help="--workload train: also time an inference-only UNet + CSPN step (eval mode, no_grad) at this batch size")
     # round 5: the default is OFF — the training-shaped leg is GPU-bound since the host path through CSPN3Function was cut from 217 to
     # 181 us per pass (it no longer matters where the scheduler puts the threads: 217.3 us unbound against 220.2 bound, headline 514.1 k
     # against 514.4 k maps/s at 200 steps, profiles/r05_bench_default_bind_{off,auto}.json), and a binding the harness applies is a
