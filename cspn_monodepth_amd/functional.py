@@ -1358,14 +1358,26 @@ def pac_forward_resident(guided, x0, sparse, T, score=None, steps_per_phase=0, s
                                         None if rp is None else ctypes.byref(rp), stream_ptr)
 
     scored = score is not None
+    # does this call run the dot-product form (cspnk_d2: K = 5, fp16 guidance and planes, one oct per thread)?  Its state is rounded to half
+    # after every step, so NO multi-launch plan has its bits: a failed call of that form is repaired by the same launch once more, unscored
+    # and with the device-side guard — which re-computes the form with its own arithmetic (csrc/cspn_repair.hip, round 6) — so that a
+    # timed-out call and a clean one return the same numbers on config 3's default path as well
+    uses_d2 = False
+    if (K == 5 and guided.dtype == torch.float16 and x0.dtype == torch.float16 and form != _lib.STEP_FMA and not steps_per_phase and not threads
+            and int(T) * (K // 2) <= _GUARD_MAX_T):
+        pd = _kres_plan_cached(K, B, H, W, int(T), int(blend), dev, 0, _dt(guided))[0]
+        uses_d2 = pd is not None and pd["quads_per_thread"] == 1
 
-    def redo(out, guided, x0, sparse, tg):     # prepare + multi-launch propagation into the same tensor (fp32: the same bits; fp16 planes:
-        from . import evaluation               # the phase-rounded schedule, within fp16 rounding of the state of the dot-product form)
+    def redo(out, guided, x0, sparse, tg):     # the same result into the same tensor: prepare + multi-launch propagation (the FMA forms: the
+        from . import evaluation               # same bits), or the guarded relaunch of the dot-product form (the same bits as well)
         if scored:
             _unscore_failed_launch(out, tg, acc)
-        wk, _ = pac_prepare(guided)
-        res, _ = propagate(wk, x0, sparse, K, int(T), blend, plan=dtype_default_plan(K, wk.dtype, None))
-        out.copy_(res)
+        if uses_d2:
+            out.copy_(pac_forward_resident(guided, x0, sparse, T, step_form=form, guard=1))
+        else:
+            wk, _ = pac_prepare(guided)
+            res, _ = propagate(wk, x0, sparse, K, int(T), blend, plan=dtype_default_plan(K, wk.dtype, None))
+            out.copy_(res)
         if scored:
             evaluation.metric_sums(out, tg, out=acc)
 

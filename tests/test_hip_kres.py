@@ -241,13 +241,45 @@ def test_resident_timeout_is_repaired_in_place(c_oracle):
             n = F.resident_fallbacks()
             F.ensure_resident_ok()
             assert F.resident_fallbacks() == n + 1
-            assert bits_equal(out, ref[:, 0])                         # the multi-launch schedule's bits (S = 4: the default plan)
             good = F.pac_forward_resident(gt, xt, None, T, step_form=form)
             if form == F.STEP_FMA:
+                assert bits_equal(out, ref[:, 0])                     # the multi-launch schedule's bits (S = 4: the default plan)
                 assert bits_equal(good, ref[:, 0])
             else:
+                # round 6: the dot-product form is repaired by a guarded relaunch of itself — a failed call returns what a clean one does
+                assert bits_equal(out, good, which="dot-product form, host repair")
                 assert float((good.float() - ref[:, 0].float()).abs().max()) <= 4e-3 * float(ref.float().abs().max())
     F.ensure_resident_ok()
+
+
+@pytest.mark.parametrize("sparse", [False, True], ids=["nosparse", "sparse"])
+def test_config3_scored_call_returns_the_same_numbers_after_a_timeout(sparse, c_oracle):
+    """BASELINE config 3's default path (the scored forward on the dot-product kernel, repaired on the host): every tile of the launch is
+    forced to give up — and so is every tile of the repair's own relaunch, which its device-side guard then re-computes — and the refined
+    depth comes out with the BITS of an undisturbed call, the metric sums as an undisturbed call accumulates them (VERDICT r5 weak #1:
+    until round 5 this was the one place where a timed-out call and a clean one legitimately returned different numbers)."""
+    import warnings
+    from cspn_monodepth_amd import evaluation as ev
+    K, B, H, W, T = 5, 24, 228, 304, 12
+    x, gd, s = inputs(c_oracle, B, H, W, K, sparse, seed=171)
+    xt, gt, st = dev(x, torch.float16), dev(gd, torch.float16), dev(s, torch.float16)
+    tg = (xt.float() + 0.1).half()
+    m = pkg.CSPN_ours.AffinityPropagate(T, state_dtype=None)
+    with torch.no_grad(), resident("on"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        acc0 = ev.new_accumulator(DEV)
+        clean = m.forward_scored(xt, gt, st, tg, acc0).clone()
+        t0, _ = ev.all_gather_metric_sums(acc0)
+        acc1 = ev.new_accumulator(DEV)
+        n = F.resident_fallbacks()
+        with _spin_limit(1):
+            out = m.forward_scored(xt, gt, st, tg, acc1)
+            t1, _ = ev.all_gather_metric_sums(acc1)              # (waits, finds the error word, repairs: the relaunch times out as well)
+        assert F.resident_fallbacks() > n
+        assert bits_equal(out, clean, which="config 3 scored forward after a forced time-out")
+        assert torch.allclose(t1, t0, rtol=1e-6, atol=0)          # (fp32 partial sums in another order)
+    F.ensure_resident_ok()
+    F.check_resident_errors()
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -443,8 +475,8 @@ KGUARD = [(5, 24, 228, 304, 12, "f16", None), (5, 24, 228, 304, 12, "f16", torch
 def test_kxk_inference_is_guarded_on_the_device(K, B, H, W, T, gd, state, sparse, c_oracle):
     """Round 5: every unscored K x K resident call carries the device-side guard (cspnk_resident_repair): all tiles are forced to
     give up, and a GPU consumer behind the call sees the finished depth.  FMA step form: the bits of the multi-launch schedule
-    with the same phase length (the guard rounds the state where that kernel does); dot-product form (config 3's default):
-    within the fp16 tolerance of the configuration, like that form itself."""
+    with the same phase length (the guard rounds the state where that kernel does); dot-product form (config 3's default): the bits
+    of a clean call of that form (round 6: the guard uses cspnk_d2's own arithmetic)."""
     import warnings
     x, g_, s = inputs(c_oracle, B, H, W, K, sparse, seed=140)
     tdt = torch.float16 if gd == "f16" else torch.float32
@@ -459,6 +491,7 @@ def test_kxk_inference_is_guarded_on_the_device(K, B, H, W, T, gd, state, sparse
     with torch.no_grad(), resident("on"), warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         for form in forms:
+            clean = F.pac_forward_resident(gt, x0, sp, T, step_form=form).clone() if form == F.STEP_DOT2 else None
             with _spin_limit(1):
                 out = F.pac_forward_resident(gt, x0, sp, T, step_form=form)
             nan_seen = torch.isnan(out).any()
@@ -466,6 +499,9 @@ def test_kxk_inference_is_guarded_on_the_device(K, B, H, W, T, gd, state, sparse
             if form == F.STEP_FMA:
                 assert bits_equal(out, ref, which="K x K FMA form, guard-repaired")
             else:
+                # round 6: the guard re-computes the dot-product form with that kernel's own arithmetic (cspn_repair.hip D2): a call whose
+                # every tile gave up returns the BITS of a clean call — and both stay within the configuration's tolerance of the phase-rounded schedule
+                assert bits_equal(out, clean, which="K x K dot-product form, guard-repaired")
                 assert float((out.float() - ref.float()).abs().max()) <= 8e-3 * float(ref.float().abs().max())
             F.ensure_resident_ok()
     F.check_resident_errors()
