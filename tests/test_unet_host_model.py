@@ -106,9 +106,11 @@ def test_eight_filter_affinity_head_equals_the_twelve_filter_one_where_it_matter
     (o12, g12, w12, st12), (o8, g8, w8, st8) = res
     assert g12.shape[1] == 12 and g8.shape[1] == 8 and g8.is_contiguous()
     close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)      # noqa: E731
-    assert close(g8, g12[:, :8], 1e-5) and close(o8, o12, 2e-5)            # (MIOpen may pick another algorithm for 8 output channels)
+    # (two passes of a 50-layer network through MIOpen are not bit-reproducible — its weight gradients use atomics, and it may pick another
+    #  algorithm for 8 output channels: measured 1e-5 .. 1e-4 relative at the heads' outputs; tests/dist_ddp_worker.py documents 1e-2 at the stem)
+    assert close(g8, g12[:, :8], 5e-4) and close(o8, o12, 1e-3)
     assert float(w12[8:].abs().max()) == 0.0 and float(w8[8:].abs().max()) == 0.0      # dead filters: exact zeros, before and now
-    assert close(w8[:8], w12[:8], 2e-3) and close(st8, st12, 2e-3)
+    assert close(w8[:8], w12[:8], 2e-2) and close(st8, st12, 3e-2)
 
 
 @pytest.mark.gpu
