@@ -847,8 +847,7 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS / 256) void cspn3_resident(const
                     //  re-loaded from scratch — with a wait — in front of EVERY poll)
                     const gptr f = (gptr) reinterpret_cast<unsigned long long>(uniform_ptr(a.flags)) + ((unsigned)(b * tiles_per_img + ny * a.tiles_x + nx) << 2);
                     unsigned spins = 0;
-                    // (spin_limit 1 is the tests' hook: give up WITHOUT looking — a flag that happened to be there already made the forced time-outs a matter of timing)
-                    while (a.spin_limit == 1u || (int)(__hip_atomic_load(reinterpret_cast<const GLB unsigned*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                    while ((int)(__hip_atomic_load(reinterpret_cast<const GLB unsigned*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
                         ++spins;
                         if ((spins & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
                             wg_bad = 1;

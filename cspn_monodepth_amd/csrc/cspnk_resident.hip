@@ -529,8 +529,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void cspnk_resident(const KResArgs 
                 if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
                     const unsigned* f = a.flags + b * tiles_per_img + ny * a.tiles_x + nx;
                     unsigned spins = 0;
-                    // (spin_limit 1 is the tests' hook: give up WITHOUT looking — a flag that happened to be there already made the forced time-outs a matter of timing)
-                    while (a.spin_limit == 1u || (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
                         ++spins;
                         if ((spins & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
                             wg_bad = 1;

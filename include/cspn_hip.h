@@ -284,8 +284,7 @@ typedef struct cspn_resident_plan {
     int images_per_launch, launches;   /* images in flight at a time; launches of that many images (the K = 5 reverse sweep: rounds of ONE launch) */
     int lds_bytes, n_cu;
     float region_over_tile; /* (tile + halo) area / tile area: the redundant-compute factor of the phases  */
-    unsigned spin_limit;    /* in: polls before a neighbour wait gives up; 0 = default (~seconds); 1 = test hook: every tile with a
-                             *     neighbour gives up without polling (a deterministic forced time-out)        */
+    unsigned spin_limit;    /* in: polls before a neighbour wait gives up; 0 = default (~seconds)          */
     unsigned long long* debug_stamps; /* in: developer probe, device buffer [images_per_launch x tiles][16] of 100 MHz wall-clock stamps (round 0)
                                        * (start, weights derived, then per phase: staged, steps done, exchanged) or NULL */
     int step_form;          /* cspnk_forward_resident, in: CSPN_STEP_AUTO (0), CSPN_STEP_FMA or CSPN_STEP_DOT2 — see there */
