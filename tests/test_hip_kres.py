@@ -235,11 +235,12 @@ def test_resident_timeout_is_repaired_in_place(c_oracle):
     with torch.no_grad():
         ref = multi_launch(xt.unsqueeze(1), gt, None, T, F.kres_plan(K, B, H, W, T)["steps_per_phase"], None)
         for form in (F.STEP_FMA, F.STEP_DOT2):
+            n = F.resident_fallbacks()
             out = F.pac_forward_resident(gt, xt, None, T, spin_limit=1, step_form=form, guard=0)      # (the HOST repair: no device-side guard)
             torch.cuda.synchronize()
-            assert bool(torch.isnan(out).any())
-            n = F.resident_fallbacks()
-            F.ensure_resident_ok()
+            if F.resident_fallbacks() == n:                           # (else: the launch protocol's own look at the error word found it
+                assert bool(torch.isnan(out).any())                   #  inside the call and the repair has happened already — timing)
+                F.ensure_resident_ok()
             assert F.resident_fallbacks() == n + 1
             good = F.pac_forward_resident(gt, xt, None, T, step_form=form)
             if form == F.STEP_FMA:

@@ -472,13 +472,20 @@ def test_repair_touches_only_the_call_that_failed(c_oracle):
         assert F.resident_fallbacks() == 1
         assert bits_equal(out_b, ref_b) and bits_equal(out_a, ref_a)       # B repaired, A left alone
         # a failed call whose inputs were overwritten before the host looked: not repairable, raised (and "on" stays on)
+        n_c = F.resident_fallbacks()
         with spin_limit(1):
             out_c = m(g_buf, d_buf)
         torch.cuda.synchronize()
-        g_buf.copy_(dev(ga))
-        with pytest.raises(F.ResidentLaunchTimeout, match="modified in place"):
-            F.ensure_resident_ok()
-        assert F._holds_poison(out_c)
+        if F.resident_fallbacks() == n_c:
+            g_buf.copy_(dev(ga))
+            with pytest.raises(F.ResidentLaunchTimeout, match="modified in place"):
+                F.ensure_resident_ok()
+            assert F._holds_poison(out_c)
+        else:
+            # the tiles gave up so quickly that the launch protocol's own look at the error word — it follows every launch — found it
+            # inside the call and repaired the result at once, before this test could overwrite the inputs: a matter of timing (one run
+            # in six on an idle box), and equally correct
+            assert bits_equal(out_c, ref_b)
     F.check_resident_errors()
 
 

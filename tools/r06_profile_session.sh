@@ -10,7 +10,7 @@ EXTRA=${EXTRA:-}
 BWD=${BWD:-1}            # 0: skip the passes over tools/run_train_leg.py (they are NYU config 2 only)
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --workload $WL $EXTRA --no-cpu-baseline --no-train-leg --cold-sets 0 --prewarm-s 0 --graph off"
+B="python $R/bench.py --workload $WL $EXTRA --no-cpu-baseline --no-train-leg --no-sparse-leg --no-stock-ops-leg --cold-sets 0 --prewarm-s 0 --graph off"
 # 1. kernel stats of the bench command (default schedule + S=1 leg), and of the S=1 schedule alone
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o bench -- $B --steps 50 --warmup 10 > $O/stats_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_s1 -o bench -- $B --steps 50 --warmup 10 --no-per-step-leg --plan ${STEP_PLAN:-1,64,57,1,1024} > $O/stats_s1.log 2>&1
