@@ -296,8 +296,8 @@ typedef struct cspn_resident_plan {
                              * cspn3_forward_resident: every form — inference, scored inference (the guard also adds the metric terms of
                              * the pixels the failed launch left unscored), training forward; cspn3_transposed_resident(_guidance);
                              * the K = 3 fp32 softmax model through cspnk_forward_resident(_history): bit-identical results.
-                             * cspnk_forward_resident, unscored: the bits of the FMA step form; for the dot-product form the
-                             * half-precision recurrence with one FMA per tap (within that form's fp16 tolerance).
+                             * cspnk_forward_resident, unscored: the bits of the FMA step form; the dot-product form is re-computed
+                             * with its own arithmetic (tap pairs, v_dot2_f32_f16 in its order, one rounding per step): its bits too.
                              * cspnk_forward_resident_history, K = 5 fp16 (the dot-product kernel): history and tap volume re-computed as
                              * cspn_pac_prepare + cspn_propagate (history) at one step per launch store them, bit for bit (the
                              * dot-product kernel's own bits are within fp16 rounding of those); cspnk_transposed_resident: bit-identical.
