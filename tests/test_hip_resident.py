@@ -813,3 +813,38 @@ def test_random_shapes_resident_equals_multi_launch(seed, c_oracle):
         done += 1
     F.ensure_resident_ok()
     assert done >= 8
+
+
+def test_eval_under_inference_mode(c_oracle):
+    """tensors made under torch.inference_mode() have no version counter; every unguarded resident launch — the default
+    scored forward among them — builds a journal entry from its inputs and crashed there AFTER the kernel had been enqueued.  The eval
+    loop's calls (plain, scored, sparse) under inference_mode return the bits they return under no_grad, and a forced time-out of the
+    scored call is still repaired."""
+    import warnings
+    from cspn_monodepth_amd import evaluation as ev
+    B, H, W, T = 3, 228, 304, 24
+    g, d, s = c_oracle.synthetic_inputs(611, B, H, W, 12, 500)
+    m = pkg.CSPN_new.AffinityPropagate(T, 3)
+    with torch.no_grad():
+        gt, dt, st = dev(g), dev(d), dev(s)
+        tg = dt + 0.1
+        acc0 = ev.new_accumulator("cuda")
+        want_plain, want_scored = m(gt, dt, st).clone(), m.forward_scored(gt, dt, st, tg, acc0).clone()
+        sums0, _ = ev.all_gather_metric_sums(acc0)
+    with torch.inference_mode(), resident("on"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        gi, di, si = dev(g), dev(d), dev(s)                 # inference tensors
+        ti = di + 0.1
+        assert gi.is_inference()
+        acc1 = ev.new_accumulator("cuda")
+        assert bits_equal(m(gi, di, si), want_plain)
+        assert bits_equal(m.forward_scored(gi, di, si, ti, acc1), want_scored)
+        sums1, _ = ev.all_gather_metric_sums(acc1)
+        assert torch.allclose(sums1, sums0, rtol=1e-12, atol=0)
+        acc2 = ev.new_accumulator("cuda")
+        with spin_limit(1):
+            out = m.forward_scored(gi, di, si, ti, acc2)    # every tile gives up; repaired where the sums are used
+            sums2, _ = ev.all_gather_metric_sums(acc2)
+        assert bits_equal(out, want_scored) and torch.allclose(sums2, sums0, rtol=1e-6, atol=0)
+    F.ensure_resident_ok()
+    F.check_resident_errors()
